@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the label-propagation hot path by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_goldens.py
+
+It imports the reference's own `src.model.predict` / `src.utils.inference_utils` with three
+in-process shims (nothing installed, nothing fetched):
+  * `loguru`  -> stub module with a no-op `logger`      (imported at src/utils/utils.py:9)
+  * `np.int`  -> `int`                                   (removed alias used at src/model/predict.py:85)
+  * `torchvision.transforms.ColorJitter` -> dummy class  (import chain inference_utils.py:15 -> transforms.py:9,50)
+and stores ONLY data (inputs' seeds/shapes and the reference's outputs) in `tests/golden/*.npz`.
+Every input is regenerated from `numpy.random.RandomState(seed)` (frozen stream) by
+`tests/golden/inputs.py`, which the tests share with this script.
+"""
+import os
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import inputs as gin  # noqa: E402  (shared deterministic input builders)
+
+REF = Path('/root/reference')
+
+
+def _install_shims():
+    np.int = int  # noqa: NPY001 - alias removed in numpy>=1.24, used by the reference
+    loguru = types.ModuleType('loguru')
+
+    class _Logger:
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+
+    loguru.logger = _Logger()
+    sys.modules['loguru'] = loguru
+    tv = types.ModuleType('torchvision')
+    tvt = types.ModuleType('torchvision.transforms')
+
+    class ColorJitter:  # only has to exist as a base class
+        def __init__(self, *a, **k):
+            pass
+
+    tvt.ColorJitter = ColorJitter
+    tv.transforms = tvt
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.transforms'] = tvt
+    sys.path.insert(0, str(REF))
+
+
+def main():
+    _install_shims()
+    torch.set_num_threads(4)
+    from src.config import Config
+    Config.DEVICE = torch.device('cpu')
+    from src.model import predict as rp
+    from src.utils import inference_utils as riu
+    from src.utils.utils import index_to_onehot
+
+    out = {}
+
+    # ---- G1: sample_frames (src/model/predict.py:74-89) -------------------------------------
+    for (rng, nref) in gin.G1_CASES:
+        rows = []
+        for fi in range(1, 121):
+            idx = rp.sample_frames(fi, rng, nref).tolist()
+            rows.append(idx + [-1] * (nref - len(idx)))
+        out[f'g1_sample_r{rng}_n{nref}'] = np.asarray(rows, dtype=np.int32)
+
+    # ---- G2: get_spatial_weight (src/model/predict.py:158-175) -----------------------------
+    out['g2_w_4x6_s8'] = rp.get_spatial_weight((4, 6), 8.0).numpy()
+    for (h, w) in gin.G2_SHAPES:
+        ii, jj = gin.g2_sample_pairs(h, w)
+        for sigma in (8.0, 21.0):
+            full = rp.get_spatial_weight((h, w), sigma)
+            out[f'g2_w_{h}x{w}_s{int(sigma)}'] = full[ii, jj].numpy()
+            del full
+
+    # ---- G3: get_labels (src/model/predict.py:92-96) ---------------------------------------
+    mask = gin.g3_mask()
+    H, W = mask.shape
+    H_d, W_d = int(np.ceil(H * 0.125)), int(np.ceil(W * 0.125))
+    d = int(mask.max()) + 1
+    lab = rp.get_labels(torch.from_numpy(mask).long(), d, H, W, H_d, W_d)
+    out['g3_labels'] = lab.numpy()
+
+    # ---- G4/G5: predict (src/model/predict.py:19-71) ---------------------------------------
+    for case in gin.PREDICT_CASES:
+        ref, tgt, lab_hist = gin.predict_inputs(case)
+        Hd, Wd = case['hw']
+        wd = rp.get_spatial_weight((Hd, Wd), case['sigma1'])
+        ws = rp.get_spatial_weight((Hd, Wd), case['sigma2'])
+        for prob in (False, True):
+            lh = gin.predict_labels(case, prob)
+            for fi in case['frame_idx']:
+                pred = rp.predict(torch.from_numpy(ref[:fi].copy()), torch.from_numpy(tgt[fi].copy()),
+                                  torch.from_numpy(lh[:, :fi].copy()),
+                                  None if prob else wd, None if prob else ws,
+                                  fi, case['range'], case['ref_num'], case['temperature'], prob)
+                out[f"{case['name']}_{'prob' if prob else 'label'}_f{fi}"] = pred.numpy().astype(np.float32)
+
+    # ---- G6: inference_single roll-out (src/utils/inference_utils.py:23-87) ----------------
+    for case in gin.ROLLOUT_CASES:
+        for prob in (False, True):
+            with tempfile.TemporaryDirectory() as td:
+                td = Path(td)
+                ann_dir = td / 'ann'
+                save_dir = td / 'save'
+                gin.write_rollout_annotation(case, ann_dir)
+                feats = gin.rollout_features(case)          # (T, C, Hd, Wd) f32
+                T = feats.shape[0]
+                H, W = case['image_hw']
+                loader = [(torch.zeros(1, 3, H, W), (case['video'],)) for _ in range(T)]
+                counter = {'i': 0}
+
+                def model(x, _f=feats, _c=counter):
+                    t = torch.from_numpy(_f[_c['i']:_c['i'] + 1].copy())
+                    _c['i'] += 1
+                    return t
+
+                preds = []
+                orig_predict = riu.predict
+
+                def spy(*a, **k):
+                    p = orig_predict(*a, **k)
+                    preds.append(p.numpy().astype(np.float32).copy())
+                    return p
+
+                riu.predict = spy
+                try:
+                    riu.inference_single(model, loader, T, ann_dir, case['video'], str(save_dir),
+                                         case['sigma1'], case['sigma2'], case['range'], case['ref_num'],
+                                         case['temperature'], prob, True)
+                finally:
+                    riu.predict = orig_predict
+                from PIL import Image
+                masks = []
+                for i in range(1, T):
+                    im = Image.open(save_dir / case['video'] / f'{i:05d}.png')
+                    assert im.mode == 'P'
+                    masks.append(np.asarray(im).astype(np.uint8))
+                    if i == 1:
+                        out[f"{case['name']}_palette"] = np.asarray(im.getpalette(), dtype=np.uint8)
+                tag = f"{case['name']}_{'prob' if prob else 'label'}"
+                out[f'{tag}_preds'] = np.stack(preds)           # (T-1, d, HW)
+                out[f'{tag}_masks'] = np.stack(masks)           # (T-1, H, W) u8
+
+    # ---- index_to_onehot (src/utils/utils.py:59-68) -----------------------------------------
+    idx = torch.from_numpy(gin.onehot_indices())
+    out['onehot'] = index_to_onehot(idx, 5).numpy()
+
+    np.savez_compressed(HERE / 'reference_goldens.npz', **out)
+    tot = sum(v.nbytes for v in out.values())
+    print(f'wrote {len(out)} arrays, {tot / 1e6:.2f} MB raw ->', HERE / 'reference_goldens.npz',
+          os.path.getsize(HERE / 'reference_goldens.npz') / 1e6, 'MB')
+
+
+if __name__ == '__main__':
+    main()
