@@ -1,0 +1,148 @@
+/*
+ * vosprop - MI355X-native label-propagation engine (C ABI, the drop-in boundary).
+ *
+ * This header is the whole boundary of the hot path.  The reference project
+ * (hynekdav/semi-supervised-VOS) has no FFI layer; the hot path is three Python call sites.
+ * Each entry point below names the reference interface (file:line in the reference tree) it
+ * replaces.  Plain C types only: pointers + sizes, no torch / HIP types (streams are void*).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative VOSPROP_E_* code; nothing throws.
+ *   - `vosprop_last_error(ctx)` gives a human-readable message for the last failure on ctx.
+ *   - pointers named *_dev are device (HBM) pointers on the ctx's GPU; *_host are host pointers.
+ *   - the engine BORROWS input buffers for the duration of the call and copies what it keeps
+ *     into its own ring; outputs are written to caller-owned device buffers.
+ *   - one ctx per (GPU, stream); a ctx is not thread-safe; there is no global state.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *     no call synchronises the device except vosprop_begin_video (host label upload) and
+ *     vosprop_destroy.
+ */
+#ifndef VOSPROP_H
+#define VOSPROP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOSPROP_ABI_VERSION 1
+
+/* error codes */
+#define VOSPROP_OK 0
+#define VOSPROP_E_INVALID (-1)      /* bad argument / configuration                       */
+#define VOSPROP_E_HIP (-2)          /* a HIP runtime call or kernel launch failed         */
+#define VOSPROP_E_STATE (-3)        /* call order violated (e.g. step before begin_video) */
+#define VOSPROP_E_UNSUPPORTED (-4)  /* valid in the reference but outside this engine     */
+#define VOSPROP_E_NOMEM (-5)
+
+/* element types of feature tensors handed to the engine */
+#define VOSPROP_DT_F32 0
+#define VOSPROP_DT_F16 1
+#define VOSPROP_DT_BF16 2
+
+/* arithmetic of the affinity contraction */
+#define VOSPROP_PREC_BF16 0 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), f32 accumulate - the fast path */
+#define VOSPROP_PREC_F32 1  /* f32-input MFMA (v_mfma_f32_32x32x2_f32), exact f32 - the parity path  */
+
+/* limits of this build */
+#define VOSPROP_MAX_CLASSES 32 /* d = objects + 1 handled per propagation pass */
+#define VOSPROP_MAX_REF 64     /* sampled reference frames per step (ref_num)  */
+#define VOSPROP_MAX_DIM 256    /* H_d, W_d <= 256 (coordinates exact in bf16)  */
+
+typedef struct vosprop_ctx vosprop_ctx;
+
+/* Mirrors the `main.py inference` options that reach the hot path
+ * (reference src/inference.py:19-31,42-43) plus the engine's own knobs. */
+typedef struct vosprop_config {
+    int abi_version;      /* must be VOSPROP_ABI_VERSION                                        */
+    int device;           /* HIP device ordinal                                                  */
+    int feat_h, feat_w;   /* H_d, W_d = ceil(H/8), ceil(W/8)  (reference src/model/predict.py:109-110) */
+    int channels;         /* C; this build requires 256 (reference src/model/vos_net.py:22-23)   */
+    int ref_num;          /* --ref_num      (src/inference.py:19), default 9                     */
+    int frame_range;      /* --frame_range  (src/inference.py:27), default 40                    */
+    float sigma1;         /* --sigma_1      (src/inference.py:28), default 8                     */
+    float sigma2;         /* --sigma_2      (src/inference.py:30), default 21                    */
+    float temperature;    /* --temperature  (src/inference.py:26), default 1; must be > 0        */
+    int probability;      /* --probability  (src/inference.py:42): 0 = propagate one-hot labels  */
+    int topk;             /* 0 = dense (the reference); k>0 = keep the k largest A[.,t] per target pixel */
+    int precision;        /* VOSPROP_PREC_*                                                      */
+    int ring_capacity;    /* 0 = auto: max(frame_range + 4, ref_num) + 1 frames                  */
+    int reserved[8];      /* zero                                                                */
+} vosprop_config;
+
+/* Fill cfg with the reference CLI defaults for a (feat_h, feat_w) map. */
+void vosprop_default_config(vosprop_config* cfg, int feat_h, int feat_w);
+
+/* Library / build information, e.g. "vosprop 0.1 gfx950".  Never NULL. */
+const char* vosprop_version(void);
+
+/* Create / destroy an engine context (allocates the feature+label ring in HBM). */
+int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg);
+void vosprop_destroy(vosprop_ctx* ctx);
+const char* vosprop_last_error(const vosprop_ctx* ctx);
+
+/* Start a video.  Replaces `prepare_first_frame` (reference src/model/predict.py:99-155, 'single'
+ * branch) minus the PNG I/O: first_label_host is the decoded 00000.png, (H,W) uint8 class indices.
+ * Computes d = max+1 (predict.py:113), the nearest-down-sampled one-hot labels (predict.py:92-96),
+ * resets the ring.  The spatial weights (predict.py:117-118, 158-175) are never materialised: the
+ * kernel evaluates them from pixel coordinates.  *d_out receives d.  Requires
+ * ceil(H/8)==feat_h, ceil(W/8)==feat_w and d <= VOSPROP_MAX_CLASSES. */
+int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H, int W, int* d_out);
+
+/* One iteration of the `inference_single` loop body after the encoder
+ * (reference src/utils/inference_utils.py:33-75):
+ *   frame 0  : stores the features in the ring (:36, feats_history = model(input)); no outputs.
+ *   frame i>0: prediction = predict(...) (:56-65, src/model/predict.py:19-71); new label =
+ *              one-hot(argmax) or the prediction itself in probability mode (:67-70); history append
+ *              (:71-72); nearest up-sample + argmax (:74-75).
+ * feat_dev   (C, H_d, W_d) in NCHW order, element type feat_dtype (the encoder output features[0]).
+ * pred_out_dev  optional (d, H_d*W_d) f32 - the reference's `prediction` tensor.
+ * mask_out_dev  optional (H, W) uint8    - the reference's per-frame mask (class indices).
+ * The frame index is kept by the engine (0,1,2,... since begin_video). */
+int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* pred_out_dev,
+                 uint8_t* mask_out_dev, void* stream);
+
+/* Frame index the NEXT vosprop_step call will process (0 right after begin_video). */
+int vosprop_frame_index(const vosprop_ctx* ctx);
+
+/* Stateless operator: the reference's
+ *   predict(ref, target, ref_label, weight_dense, weight_sparse, frame_idx, range, ref_num,
+ *           temperature, probability_propagation)            (src/model/predict.py:19-28)
+ * with the two (HW,HW) weight matrices replaced by their sigmas.
+ *   ref_dev       (T, C, H_d, W_d)   history features, element type feat_dtype, T >= frame_idx
+ *   target_dev    (C, H_d, W_d)
+ *   ref_label_dev (d, T, H_d*W_d)    f32 (one-hot or probabilities)
+ *   out_dev       (d, H_d*W_d)       f32
+ * Uses ctx's GPU, precision, top-k and scratch ring; ctx must have ring_capacity >= ref_num + 1.
+ * Does not touch the video state of ctx. */
+int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_dev, int feat_dtype,
+                    const float* ref_label_dev, int T, int d, int frame_idx, int frame_range, int ref_num,
+                    float temperature, float sigma1, float sigma2, int probability, float* out_dev,
+                    void* stream);
+
+/* Frame sampler, reference `sample_frames` (src/model/predict.py:74-89).  Host-side, exact.
+ * out must hold num_refs ints (or frame_idx when frame_idx <= num_refs); returns the count. */
+int vosprop_sample_frames(int frame_idx, int frame_range, int num_refs, int* out);
+
+/* Timing / introspection of the last propagation on ctx (for bench.py and the roofline line). */
+typedef struct vosprop_stats {
+    int n_ref;              /* sampled reference frames N                          */
+    int hw;                 /* H_d*W_d                                             */
+    int workgroups;         /* grid of the propagation kernel                      */
+    int tiles_per_wg;       /* reference tiles (32 rows) each workgroup walks      */
+    double flops;           /* algorithmic FLOP of the step: 2*N*HW^2*C + 2*d*N*HW^2 */
+    double bytes;           /* algorithmic bytes: N*HW*C*2 + HW*C*2 + N*HW + d*HW*4   */
+} vosprop_stats;
+int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out);
+
+/* Measure the propagation kernel alone: re-runs the last step's propagation `iters` times on
+ * `stream` between HIP events recorded on that stream and returns the mean kernel time in
+ * microseconds (bench.py's roofline.achieved).  Outputs are rewritten identically. */
+int vosprop_time_last_propagation(vosprop_ctx* ctx, int iters, void* stream, double* mean_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOSPROP_H */

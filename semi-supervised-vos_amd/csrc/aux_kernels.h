@@ -1,0 +1,141 @@
+// Small HBM-bound kernels either side of the propagation kernel: feature push (NCHW -> pixel-major bf16),
+// label packing into MFMA A-operand order, partial combine + argmax, nearest up-sampling of the mask.
+#pragma once
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+namespace vosprop {
+
+template <typename T> __device__ inline float to_f32(T v);
+template <> __device__ inline float to_f32<float>(float v) { return v; }
+template <> __device__ inline float to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ inline float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+// Replaces reference src/model/predict.py:47 (permute(0,2,3,1).reshape) + the history append
+// (src/utils/inference_utils.py:72): (C, HW) channel-major -> ring slot [HWp][C] pixel-major bf16.
+// grid = ceil(HW/64), block = 256.  Rows >= HW of the slot stay zero (set once at allocation).
+template <typename T>
+__global__ __launch_bounds__(256) void push_kernel(const T* __restrict__ src, bf16_t* __restrict__ dst, int HW) {
+    __shared__ float tile[64][65];
+    const int p0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int cc = 0; cc < kC; cc += 64) {
+        const int p = tid & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ch = i * 4 + (tid >> 6);
+            float v = 0.0f;
+            if (p0 + p < HW) v = to_f32<T>(src[(size_t)(cc + ch) * HW + p0 + p]);
+            tile[ch][p] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int px = pass * 32 + (tid >> 3);
+            const int c8 = (tid & 7) * 8;
+            if (p0 + px < HW) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)tile[c8 + e][px];
+                *(bf16x8*)(dst + (size_t)(p0 + px) * kC + cc + c8) = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Element (s, lane, e) of a label tile is L[class = lane & 31][row = 16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)]:
+// the A-operand order that matches an accumulator tile reused as the B operand (see prop_bf16.h).
+__device__ inline int lab_row(int s, int lane, int e) { return 16 * s + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3); }
+
+// One-hot labels from a class-index map (reference index_to_onehot, src/utils/utils.py:59-68).
+// One thread per 16-byte chunk: grid*block >= tiles*128.
+__global__ void pack_cls_kernel(const uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi, int HW, int tiles) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= tiles * 128) return;
+    const int tile = gid >> 7, s = (gid >> 6) & 1, lane = gid & 63;
+    const int k = lane & 31;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int p = tile * kTileR + lab_row(s, lane, e);
+        o[e] = (bf16_t)((p < HW && cls[p] == k) ? 1.0f : 0.0f);
+    }
+    *(bf16x8*)(lab_hi + (size_t)gid * 8) = o;
+}
+
+// General f32 labels L[k][p] (row stride ld floats between classes) -> hi (+ lo) bf16 parts.
+__global__ void pack_f32_kernel(const float* __restrict__ L, size_t ld, int d, bf16_t* __restrict__ lab_hi,
+                                bf16_t* __restrict__ lab_lo, int HW, int tiles) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= tiles * 128) return;
+    const int tile = gid >> 7, s = (gid >> 6) & 1, lane = gid & 63;
+    const int k = lane & 31;
+    bf16x8 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int p = tile * kTileR + lab_row(s, lane, e);
+        float v = 0.0f;
+        if (p < HW && k < d) v = L[(size_t)k * ld + p];
+        const float hi = bf16_round(v);
+        oh[e] = (bf16_t)hi;
+        ol[e] = (bf16_t)(v - hi);
+    }
+    *(bf16x8*)(lab_hi + (size_t)gid * 8) = oh;
+    if (lab_lo) *(bf16x8*)(lab_lo + (size_t)gid * 8) = ol;
+}
+
+// Merge the per-unit partials of one target pixel, normalise, arg-max.
+//   out[k,t] = sum_u Y_u[k] 2^((m_u - M) c) / sum_u l_u 2^((m_u - M) c)      (reference predict.py:55-70)
+//   cls[t]   = argmax_k out[k,t], first maximum wins (reference inference_utils.py:70, torch.argmax on CPU)
+// grid = TT, block = 256 (one thread per target pixel of the tile).
+__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ part, int U, int d, int HW, float c,
+                                                      float* __restrict__ pred, uint8_t* __restrict__ cls) {
+    const int tt = blockIdx.x, col = threadIdx.x;
+    const int t = tt * kBT + col;
+    if (t >= HW) return;
+    const size_t ustride = (size_t)(2 + d) * kBT;
+    const float* base = part + (size_t)tt * U * ustride + col;
+    float M = -3.0e38f;
+    for (int u = 0; u < U; ++u) M = fmaxf(M, base[u * ustride]);
+    float Lsum = 0.0f;
+    float acc[kMaxClasses];
+#pragma unroll
+    for (int k = 0; k < kMaxClasses; ++k) acc[k] = 0.0f;
+    for (int u = 0; u < U; ++u) {
+        const float* pu = base + u * ustride;
+        const float sc = __builtin_amdgcn_exp2f((pu[0] - M) * c);
+        Lsum += pu[kBT] * sc;
+#pragma unroll
+        for (int k = 0; k < kMaxClasses; ++k)
+            if (k < d) acc[k] += pu[(size_t)(2 + k) * kBT] * sc;
+    }
+    const float inv = 1.0f / Lsum;
+    int best = 0;
+    float bv = acc[0] * inv;
+#pragma unroll
+    for (int k = 0; k < kMaxClasses; ++k) {
+        if (k < d) {
+            const float v = acc[k] * inv;
+            pred[(size_t)k * HW + t] = v;
+            if (v > bv) { bv = v; best = k; }
+        }
+    }
+    cls[t] = (uint8_t)best;
+}
+
+// Nearest up-sampling of the class map (reference inference_utils.py:74-75; argmax and nearest
+// interpolation commute, so the index map is up-sampled instead of the d-channel prediction).
+// ATen's nearest source index: min(floor(dst * (float)in/out), in-1).
+__global__ void upsample_kernel(const uint8_t* __restrict__ cls, int Hd, int Wd, uint8_t* __restrict__ mask, int H, int W) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const float sy = (float)Hd / (float)H, sx = (float)Wd / (float)W;
+    int iy = (int)floorf((float)y * sy), ix = (int)floorf((float)x * sx);
+    iy = iy < Hd - 1 ? iy : Hd - 1;
+    ix = ix < Wd - 1 ? ix : Wd - 1;
+    mask[(size_t)y * W + x] = cls[iy * Wd + ix];
+}
+
+}  // namespace vosprop

@@ -1,0 +1,487 @@
+// vosprop engine: host side of the C ABI declared in include/vosprop.h.
+// Owns the feature/label ring in HBM, plans each propagation, launches the HIP kernels.
+#include "../../include/vosprop.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "aux_kernels.h"
+#include "common.h"
+#include "prop_bf16.h"
+
+using namespace vosprop;
+
+namespace {
+
+struct Ring {
+    bf16_t* feat = nullptr;    // [cap][HWp][kC]
+    bf16_t* lab_hi = nullptr;  // [cap][tiles][2][64][8]
+    bf16_t* lab_lo = nullptr;
+    uint8_t* cls = nullptr;    // [cap][HWp]
+    int cap = 0;
+};
+
+struct LastProp {
+    bool valid = false;
+    PropArgs args;
+    int grid = 0;
+    bool prob = false, lab_lo = false;
+};
+
+}  // namespace
+
+struct vosprop_ctx {
+    vosprop_config cfg;
+    int HW = 0, HWp = 0, tiles = 0, TT = 0;
+    Ring ring;            // video state
+    Ring scratch;         // stateless vosprop_predict
+    bf16_t* coord_tab = nullptr;
+    float* part = nullptr;
+    size_t part_bytes = 0;
+    float* pred_buf = nullptr;     // (kMaxClasses, HW) f32
+    uint8_t* cls_tmp = nullptr;    // (HWp)
+    // video state
+    bool in_video = false;
+    int frame_idx = 0;
+    int d = 0, H = 0, W = 0;
+    LastProp last;
+    vosprop_stats stats;
+    std::string err;
+};
+
+namespace {
+
+int fail(vosprop_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                               \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(ctx, VOSPROP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+int ring_alloc(vosprop_ctx* ctx, Ring& r, int cap) {
+    const size_t feat_b = (size_t)cap * ctx->HWp * kC * sizeof(bf16_t);
+    const size_t lab_b = (size_t)cap * ctx->tiles * 2 * 64 * 8 * sizeof(bf16_t);
+    const size_t cls_b = (size_t)cap * ctx->HWp;
+    HIP_TRY(ctx, hipMalloc((void**)&r.feat, feat_b));
+    HIP_TRY(ctx, hipMalloc((void**)&r.lab_hi, lab_b));
+    HIP_TRY(ctx, hipMalloc((void**)&r.lab_lo, lab_b));
+    HIP_TRY(ctx, hipMalloc((void**)&r.cls, cls_b));
+    HIP_TRY(ctx, hipMemset(r.feat, 0, feat_b));
+    HIP_TRY(ctx, hipMemset(r.lab_hi, 0, lab_b));
+    HIP_TRY(ctx, hipMemset(r.lab_lo, 0, lab_b));
+    HIP_TRY(ctx, hipMemset(r.cls, 0, cls_b));
+    r.cap = cap;
+    return VOSPROP_OK;
+}
+
+void ring_free(Ring& r) {
+    if (r.feat) (void)hipFree(r.feat);
+    if (r.lab_hi) (void)hipFree(r.lab_hi);
+    if (r.lab_lo) (void)hipFree(r.lab_lo);
+    if (r.cls) (void)hipFree(r.cls);
+    r = Ring();
+}
+
+// Reference-side spatial channels, [tile][half][row][8]: per pixel p=(a,b):
+//   ch0-2: a   ch3-5: b   ch6-8: Qh   ch9-10: Qm   ch11: Ql   ch12-15: 0,   Q = a^2 + (2/W) a b + (1 + 1/W^2) b^2.
+int build_coord_table(vosprop_ctx* ctx) {
+    const int W = ctx->cfg.feat_w;
+    std::vector<uint16_t> tab((size_t)ctx->HWp * kCoordCh, 0);
+    const double tw = 2.0 / W, gm = 1.0 + 1.0 / ((double)W * W);
+    for (int p = 0; p < ctx->HW; ++p) {
+        const double a = p / W, b = p % W;
+        const double Q = a * a + tw * a * b + gm * b * b;
+        const float qh = bf16_round((float)Q);
+        const float qm = bf16_round((float)(Q - qh));
+        const float ql = bf16_round((float)(Q - qh - qm));
+        float ch[kCoordCh] = {(float)a, (float)a, (float)a, (float)b, (float)b, (float)b, qh, qh, qh, qm, qm, ql, 0, 0, 0, 0};
+        const int tile = p / kTileR, row = p % kTileR;
+        for (int c = 0; c < kCoordCh; ++c)
+            tab[(((size_t)tile * 2 + c / 8) * 32 + row) * 8 + (c % 8)] = bf16_bits(ch[c]);
+    }
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->coord_tab, tab.size() * 2));
+    HIP_TRY(ctx, hipMemcpy(ctx->coord_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    return VOSPROP_OK;
+}
+
+int ensure_part(vosprop_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->part_bytes) return VOSPROP_OK;
+    if (ctx->part) (void)hipFree(ctx->part);
+    ctx->part = nullptr;
+    ctx->part_bytes = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->part, bytes));
+    ctx->part_bytes = bytes;
+    return VOSPROP_OK;
+}
+
+// How many workgroups split one (target tile, reference frame): minimise rounds x tiles per workgroup.
+int plan_row_splits(int TT, int n_ref, int tiles) {
+    const int slots = 256;   // one 8-wave workgroup per CU
+    int best = 1;
+    long best_cost = -1;
+    for (int rs = 1; rs <= 8; ++rs) {
+        const long wgs = (long)TT * n_ref * rs;
+        const long rounds = (wgs + slots - 1) / slots;
+        const long per = (tiles + rs - 1) / rs + 4;   // +4 tiles ~ prologue/epilogue of a workgroup
+        const long cost = rounds * per;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rs; }
+    }
+    return best;
+}
+
+template <typename T>
+void launch_push(const void* src, bf16_t* dst, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(push_kernel<T>, dim3((HW + 63) / 64), dim3(256), 0, s, (const T*)src, dst, HW);
+}
+
+int push_features(vosprop_ctx* ctx, const void* src, int dtype, bf16_t* dst, hipStream_t s) {
+    switch (dtype) {
+        case VOSPROP_DT_F32: launch_push<float>(src, dst, ctx->HW, s); break;
+        case VOSPROP_DT_F16: launch_push<__half>(src, dst, ctx->HW, s); break;
+        case VOSPROP_DT_BF16: launch_push<bf16_t>(src, dst, ctx->HW, s); break;
+        default: return fail(ctx, VOSPROP_E_INVALID, "unknown feature dtype");
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return VOSPROP_OK;
+}
+
+void launch_prop(const LastProp& lp, hipStream_t s) {
+    const dim3 grid(lp.grid), block(kWaves * 64);
+    if (lp.prob) {
+        if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<true, true>), grid, block, 0, s, lp.args);
+        else hipLaunchKernelGGL((prop_bf16_kernel<true, false>), grid, block, 0, s, lp.args);
+    } else {
+        if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<false, true>), grid, block, 0, s, lp.args);
+        else hipLaunchKernelGGL((prop_bf16_kernel<false, false>), grid, block, 0, s, lp.args);
+    }
+}
+
+// One propagation: sampled frames `idx` (history indices, ring slot = idx % cap) against the target slot.
+int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int frame_idx, int target_slot, int d,
+              bool prob, bool lab_lo, float sigma1, float sigma2, float temperature, float* pred, uint8_t* cls,
+              hipStream_t s) {
+    if (n_ref < 1 || n_ref > kMaxRef) return fail(ctx, VOSPROP_E_INVALID, "n_ref out of range");
+    if (d < 1 || d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "d > VOSPROP_MAX_CLASSES");
+    if (!(temperature > 0.0f)) return fail(ctx, VOSPROP_E_UNSUPPORTED, "temperature must be > 0");
+    if (ctx->cfg.precision != VOSPROP_PREC_BF16) return fail(ctx, VOSPROP_E_UNSUPPORTED, "precision not built");
+    if (ctx->cfg.topk != 0) return fail(ctx, VOSPROP_E_UNSUPPORTED, "top-k not built yet");
+    LastProp lp;
+    PropArgs& a = lp.args;
+    memset(&a, 0, sizeof(a));
+    a.feat_ring = ring.feat;
+    a.coord_tab = ctx->coord_tab;
+    a.lab_hi = ring.lab_hi;
+    a.lab_lo = lab_lo ? ring.lab_lo : nullptr;
+    for (int n = 0; n < n_ref; ++n) a.slot[n] = slots[n];
+    a.sparse_mask = 0;
+    if (!prob && frame_idx > 15)   // reference src/model/predict.py:59-64
+        for (int n = 0; n < n_ref - kContinuousFrame; ++n) a.sparse_mask |= 1ull << n;
+    a.target_slot = target_slot;
+    a.n_ref = n_ref;
+    a.HW = ctx->HW;
+    a.HWp = ctx->HWp;
+    a.Wd = ctx->cfg.feat_w;
+    a.d = d;
+    a.tiles_per_frame = ctx->tiles;
+    a.row_splits = plan_row_splits(ctx->TT, n_ref, ctx->tiles);
+    a.tiles_per_split = (ctx->tiles + a.row_splits - 1) / a.row_splits;
+    a.c = (float)((double)temperature * 1.4426950408889634);
+    a.g1 = 1.0 / ((double)sigma1 * sigma1 * temperature);
+    a.g2 = 1.0 / ((double)sigma2 * sigma2 * temperature);
+    a.two_over_w = 2.0 / ctx->cfg.feat_w;
+    a.gamma = 1.0 + 1.0 / ((double)ctx->cfg.feat_w * ctx->cfg.feat_w);
+    const int U = n_ref * a.row_splits;
+    lp.grid = ctx->TT * U;
+    lp.prob = prob;
+    lp.lab_lo = lab_lo;
+    int rc = ensure_part(ctx, (size_t)lp.grid * (2 + d) * kBT * sizeof(float));
+    if (rc) return rc;
+    a.part = ctx->part;
+    launch_prop(lp, s);
+    HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(combine_kernel, dim3(ctx->TT), dim3(kBT), 0, s, ctx->part, U, d, ctx->HW, a.c, pred, cls);
+    HIP_TRY(ctx, hipGetLastError());
+    lp.valid = true;
+    ctx->last = lp;
+    vosprop_stats& st = ctx->stats;
+    const double HW = ctx->HW;
+    st.n_ref = n_ref;
+    st.hw = ctx->HW;
+    st.workgroups = lp.grid;
+    st.tiles_per_wg = a.tiles_per_split;
+    st.flops = 2.0 * n_ref * HW * HW * kC + 2.0 * d * n_ref * HW * HW;
+    st.bytes = n_ref * HW * kC * 2.0 + HW * kC * 2.0 + n_ref * HW + d * HW * 4.0;
+    return VOSPROP_OK;
+}
+
+int pack_labels_from_cls(vosprop_ctx* ctx, const uint8_t* cls, bf16_t* lab_hi, hipStream_t s) {
+    const int n = ctx->tiles * 128;
+    hipLaunchKernelGGL(pack_cls_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cls, lab_hi, ctx->HW, ctx->tiles);
+    HIP_TRY(ctx, hipGetLastError());
+    return VOSPROP_OK;
+}
+
+int pack_labels_from_f32(vosprop_ctx* ctx, const float* L, size_t ld, int d, bf16_t* lab_hi, bf16_t* lab_lo,
+                         hipStream_t s) {
+    const int n = ctx->tiles * 128;
+    hipLaunchKernelGGL(pack_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, L, ld, d, lab_hi, lab_lo, ctx->HW,
+                       ctx->tiles);
+    HIP_TRY(ctx, hipGetLastError());
+    return VOSPROP_OK;
+}
+
+size_t dtype_size(int dt) { return dt == VOSPROP_DT_F32 ? 4 : 2; }
+
+// ATen nearest-neighbour source index (see aux_kernels.h upsample_kernel)
+inline int nearest_src(int dst, int in_size, int out_size) {
+    const float scale = (float)in_size / (float)out_size;
+    int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* vosprop_version(void) { return "vosprop 0.1 (gfx950, bf16 MFMA)"; }
+
+void vosprop_default_config(vosprop_config* cfg, int feat_h, int feat_w) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->abi_version = VOSPROP_ABI_VERSION;
+    cfg->device = 0;
+    cfg->feat_h = feat_h;
+    cfg->feat_w = feat_w;
+    cfg->channels = kC;
+    cfg->ref_num = 9;
+    cfg->frame_range = 40;
+    cfg->sigma1 = 8.0f;
+    cfg->sigma2 = 21.0f;
+    cfg->temperature = 1.0f;
+    cfg->probability = 0;
+    cfg->topk = 0;
+    cfg->precision = VOSPROP_PREC_BF16;
+    cfg->ring_capacity = 0;
+}
+
+int vosprop_sample_frames(int frame_idx, int frame_range, int num_refs, int* out) {
+    // reference src/model/predict.py:74-89; float64 linspace + truncation, as numpy does it
+    int n = 0;
+    if (frame_idx <= num_refs) {
+        for (int i = 0; i < frame_idx; ++i) out[n++] = i;
+        return n;
+    }
+    const int dense_num = kContinuousFrame - 1;
+    const int sparse_num = num_refs - dense_num;
+    const int ref_end = frame_idx - dense_num - 1;
+    const int ref_start = ref_end - frame_range > 0 ? ref_end - frame_range : 0;
+    if (sparse_num == 1) {
+        out[n++] = ref_start;
+    } else if (sparse_num > 1) {
+        const double step = (double)(ref_end - ref_start) / (double)(sparse_num - 1);
+        for (int k = 0; k < sparse_num; ++k)
+            out[n++] = (k == sparse_num - 1) ? ref_end : (int)((double)ref_start + k * step);
+    }
+    for (int jj = 0; jj < dense_num; ++jj) out[n++] = frame_idx - dense_num + jj;
+    return n;
+}
+
+int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
+    if (!out || !cfg) return VOSPROP_E_INVALID;
+    *out = nullptr;
+    if (cfg->abi_version != VOSPROP_ABI_VERSION) return VOSPROP_E_INVALID;
+    if (cfg->channels != kC) return VOSPROP_E_UNSUPPORTED;
+    if (cfg->feat_h < 1 || cfg->feat_w < 1 || cfg->feat_h > VOSPROP_MAX_DIM || cfg->feat_w > VOSPROP_MAX_DIM)
+        return VOSPROP_E_UNSUPPORTED;
+    if (cfg->ref_num < 1 || cfg->ref_num > kMaxRef || cfg->frame_range < 0) return VOSPROP_E_INVALID;
+    if (!(cfg->temperature > 0.0f) || !(cfg->sigma1 > 0.0f) || !(cfg->sigma2 > 0.0f)) return VOSPROP_E_INVALID;
+    if (cfg->precision != VOSPROP_PREC_BF16) return VOSPROP_E_UNSUPPORTED;
+    if (cfg->topk != 0) return VOSPROP_E_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return VOSPROP_E_HIP;
+    if (hipSetDevice(cfg->device) != hipSuccess) return VOSPROP_E_HIP;
+    vosprop_ctx* ctx = new (std::nothrow) vosprop_ctx();
+    if (!ctx) return VOSPROP_E_NOMEM;
+    ctx->cfg = *cfg;
+    ctx->HW = cfg->feat_h * cfg->feat_w;
+    ctx->HWp = (ctx->HW + kTileR - 1) / kTileR * kTileR;
+    ctx->tiles = ctx->HWp / kTileR;
+    ctx->TT = (ctx->HW + kBT - 1) / kBT;
+    int cap = cfg->ring_capacity;
+    const int need = (cfg->frame_range + kContinuousFrame > cfg->ref_num ? cfg->frame_range + kContinuousFrame : cfg->ref_num) + 1;
+    if (cap == 0) cap = need;
+    if (cap < cfg->ref_num + 1) { delete ctx; return VOSPROP_E_INVALID; }
+    ctx->cfg.ring_capacity = cap;
+    int rc = ring_alloc(ctx, ctx->ring, cap);
+    if (!rc) rc = build_coord_table(ctx);
+    if (!rc && hipMalloc((void**)&ctx->pred_buf, (size_t)kMaxClasses * ctx->HW * sizeof(float)) != hipSuccess) rc = VOSPROP_E_HIP;
+    if (!rc && hipMalloc((void**)&ctx->cls_tmp, (size_t)ctx->HWp) != hipSuccess) rc = VOSPROP_E_HIP;
+    if (rc) { vosprop_destroy(ctx); return rc; }
+    *out = ctx;
+    return VOSPROP_OK;
+}
+
+void vosprop_destroy(vosprop_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    (void)hipDeviceSynchronize();
+    ring_free(ctx->ring);
+    ring_free(ctx->scratch);
+    if (ctx->coord_tab) (void)hipFree(ctx->coord_tab);
+    if (ctx->part) (void)hipFree(ctx->part);
+    if (ctx->pred_buf) (void)hipFree(ctx->pred_buf);
+    if (ctx->cls_tmp) (void)hipFree(ctx->cls_tmp);
+    delete ctx;
+}
+
+const char* vosprop_last_error(const vosprop_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int vosprop_frame_index(const vosprop_ctx* ctx) { return ctx && ctx->in_video ? ctx->frame_idx : -1; }
+
+int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H, int W, int* d_out) {
+    if (!ctx || !first_label_host || H < 1 || W < 1) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
+    const int Hd = (int)std::ceil(H * 0.125), Wd = (int)std::ceil(W * 0.125);   // reference predict.py:109-110
+    if (Hd != ctx->cfg.feat_h || Wd != ctx->cfg.feat_w)
+        return fail(ctx, VOSPROP_E_INVALID, "image size does not match the engine's feature map");
+    int mx = 0;
+    for (size_t i = 0; i < (size_t)H * W; ++i) mx = first_label_host[i] > mx ? first_label_host[i] : mx;
+    const int d = mx + 1;   // reference predict.py:113
+    if (d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "more than VOSPROP_MAX_CLASSES classes");
+    std::vector<uint8_t> cls((size_t)ctx->HWp, 0);
+    for (int y = 0; y < Hd; ++y) {   // reference get_labels, predict.py:92-96 (one-hot + nearest == nearest of indices)
+        const int sy = nearest_src(y, H, Hd);
+        for (int x = 0; x < Wd; ++x) cls[(size_t)y * Wd + x] = first_label_host[(size_t)sy * W + nearest_src(x, W, Wd)];
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(ctx->ring.cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
+    int rc = pack_labels_from_cls(ctx, ctx->ring.cls, ctx->ring.lab_hi, nullptr);
+    if (rc) return rc;
+    const size_t lab_slot_b = (size_t)ctx->tiles * 2 * 64 * 8 * sizeof(bf16_t);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ring.lab_lo, 0, lab_slot_b, nullptr));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->in_video = true;
+    ctx->frame_idx = 0;
+    ctx->d = d;
+    ctx->H = H;
+    ctx->W = W;
+    if (d_out) *d_out = d;
+    return VOSPROP_OK;
+}
+
+int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* pred_out_dev, uint8_t* mask_out_dev,
+                 void* stream) {
+    if (!ctx || !feat_dev) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
+    if (!ctx->in_video) return fail(ctx, VOSPROP_E_STATE, "vosprop_step before vosprop_begin_video");
+    hipStream_t s = (hipStream_t)stream;
+    Ring& R = ctx->ring;
+    const int f = ctx->frame_idx;
+    const int slot = f % R.cap;
+    const size_t lab_slot = (size_t)ctx->tiles * 2 * 64 * 8;
+    int rc = push_features(ctx, feat_dev, feat_dtype, R.feat + (size_t)slot * ctx->HWp * kC, s);
+    if (rc) return rc;
+    if (f == 0) {   // reference inference_utils.py:33-48: frame 0 only seeds the history
+        ctx->frame_idx = 1;
+        return VOSPROP_OK;
+    }
+    int idx[kMaxRef], slots[kMaxRef];
+    const int n_ref = vosprop_sample_frames(f, ctx->cfg.frame_range, ctx->cfg.ref_num, idx);
+    for (int n = 0; n < n_ref; ++n) slots[n] = idx[n] % R.cap;
+    const bool prob = ctx->cfg.probability != 0;
+    uint8_t* cls_slot = R.cls + (size_t)slot * ctx->HWp;
+    rc = propagate(ctx, R, slots, n_ref, f, slot, ctx->d, prob, prob, ctx->cfg.sigma1, ctx->cfg.sigma2,
+                   ctx->cfg.temperature, ctx->pred_buf, cls_slot, s);
+    if (rc) return rc;
+    // new label of this frame (reference inference_utils.py:67-71)
+    if (prob) rc = pack_labels_from_f32(ctx, ctx->pred_buf, (size_t)ctx->HW, ctx->d, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s);
+    else rc = pack_labels_from_cls(ctx, cls_slot, R.lab_hi + slot * lab_slot, s);
+    if (rc) return rc;
+    if (pred_out_dev)
+        HIP_TRY(ctx, hipMemcpyAsync(pred_out_dev, ctx->pred_buf, (size_t)ctx->d * ctx->HW * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (mask_out_dev) {   // reference inference_utils.py:74-75
+        hipLaunchKernelGGL(upsample_kernel, dim3((ctx->W + 255) / 256, ctx->H), dim3(256), 0, s, cls_slot, ctx->cfg.feat_h,
+                           ctx->cfg.feat_w, mask_out_dev, ctx->H, ctx->W);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    ctx->frame_idx = f + 1;
+    return VOSPROP_OK;
+}
+
+int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_dev, int feat_dtype,
+                    const float* ref_label_dev, int T, int d, int frame_idx, int frame_range, int ref_num,
+                    float temperature, float sigma1, float sigma2, int probability, float* out_dev, void* stream) {
+    if (!ctx || !ref_dev || !target_dev || !ref_label_dev || !out_dev) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
+    if (frame_idx < 1 || frame_idx > T) return fail(ctx, VOSPROP_E_INVALID, "frame_idx must be in [1, T]");
+    if (ref_num < 1 || ref_num > kMaxRef) return fail(ctx, VOSPROP_E_INVALID, "ref_num out of range");
+    if (d < 1 || d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "d > VOSPROP_MAX_CLASSES");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    if (ctx->scratch.cap < ref_num + 1) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        ring_free(ctx->scratch);
+        int rc = ring_alloc(ctx, ctx->scratch, ref_num + 1);
+        if (rc) return rc;
+    }
+    Ring& R = ctx->scratch;
+    std::vector<int> idx((size_t)(frame_idx > ref_num ? frame_idx : ref_num));
+    const int n_ref = vosprop_sample_frames(frame_idx, frame_range, ref_num, idx.data());
+    const size_t esz = dtype_size(feat_dtype);
+    const size_t frame_elems = (size_t)kC * ctx->HW;
+    const size_t lab_slot = (size_t)ctx->tiles * 2 * 64 * 8;
+    int slots[kMaxRef];
+    for (int n = 0; n < n_ref; ++n) {
+        slots[n] = n;
+        int rc = push_features(ctx, (const unsigned char*)ref_dev + (size_t)idx[n] * frame_elems * esz, feat_dtype,
+                               R.feat + (size_t)n * ctx->HWp * kC, s);
+        if (rc) return rc;
+        // ref_label (d, T, HW): class stride T*HW floats, frame idx[n]
+        rc = pack_labels_from_f32(ctx, ref_label_dev + (size_t)idx[n] * ctx->HW, (size_t)T * ctx->HW, d,
+                                  R.lab_hi + n * lab_slot, R.lab_lo + n * lab_slot, s);
+        if (rc) return rc;
+    }
+    int rc = push_features(ctx, target_dev, feat_dtype, R.feat + (size_t)n_ref * ctx->HWp * kC, s);
+    if (rc) return rc;
+    return propagate(ctx, R, slots, n_ref, frame_idx, n_ref, d, probability != 0, true, sigma1, sigma2, temperature,
+                     out_dev, ctx->cls_tmp, s);
+}
+
+int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out) {
+    if (!ctx || !out) return VOSPROP_E_INVALID;
+    if (!ctx->last.valid) return VOSPROP_E_STATE;
+    *out = ctx->stats;
+    return VOSPROP_OK;
+}
+
+int vosprop_time_last_propagation(vosprop_ctx* ctx, int iters, void* stream, double* mean_us) {
+    if (!ctx || !mean_us || iters < 1) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
+    if (!ctx->last.valid) return fail(ctx, VOSPROP_E_STATE, "no propagation has run on this context");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    launch_prop(ctx->last, s);   // warm
+    HIP_TRY(ctx, hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch_prop(ctx->last, s);
+    HIP_TRY(ctx, hipEventRecord(e1, s));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_TRY(ctx, hipGetLastError());
+    *mean_us = (double)ms * 1000.0 / iters;
+    return VOSPROP_OK;
+}
+
+}  // extern "C"
