@@ -1,0 +1,120 @@
+"""Encoder with the reference's interface: `VOSNet(model)`; `forward((B,3,H,W)) -> (B,256,ceil(H/8),ceil(W/8))`.
+
+Mirrors reference src/model/vos_net.py:9-54 and the truncated ResNet of src/model/backbone/resnet.py:99-150
+(children [0:8]: stem + layer1..layer4, layer3/layer4 at stride 1 so the output stride is 8;
+`adjust_dim` 1x1 conv + `bn256` for resnet50/101).  Module / state-dict names are identical
+(`backbone.{0,1,4,5,6,7}.*`, `adjust_dim.weight`, `bn256.*`) so reference checkpoints load unchanged.
+
+Differences, on purpose:
+  * construction never touches the network (the reference calls model_zoo.load_url at vos_net.py:17,20,25);
+    weights come from `load_model` / `--resume` only.  `model='facebook'` needs torch.hub -> clear error.
+  * it runs as stock PyTorch-ROCm modules (MIOpen); `prepare_for_inference` switches to channels_last + bf16/f16,
+    the MI355X-friendly layout for the 1x1/3x3 convolutions.  The propagation step, not the encoder, is the
+    hand-written HIP part of this project.
+"""
+import torch
+import torch.nn as nn
+
+# (block kind, blocks per stage) - reference resnet.py:159-216
+_ARCH = {
+    'resnet18': ('basic', (2, 2, 2, 2)),
+    'resnet34': ('basic', (3, 4, 6, 3)),
+    'resnet50': ('bottleneck', (3, 4, 6, 3)),
+    'resnet101': ('bottleneck', (3, 4, 23, 3)),
+}
+_STAGE_PLANES = (64, 128, 256, 256)     # layer4 has planes=256, not 512 (reference resnet.py:112)
+_STAGE_STRIDES = (1, 2, 1, 1)           # layer3 / layer4 keep stride 1 (reference resnet.py:111-112)
+
+
+def _conv(cin, cout, k, stride=1):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=k // 2, bias=False)
+
+
+class ResidualUnit(nn.Module):
+    """Basic (3x3,3x3) or bottleneck (1x1,3x3,1x1 with x4 expansion) residual unit.  Sub-module names follow
+    the reference blocks (resnet.py:28-95): conv1/bn1/conv2/bn2[/conv3/bn3], downsample.{0,1}."""
+
+    def __init__(self, kind, cin, planes, stride):
+        super().__init__()
+        self.kind = kind
+        if kind == 'basic':
+            cout = planes
+            self.conv1, self.bn1 = _conv(cin, planes, 3, stride), nn.BatchNorm2d(planes)
+            self.conv2, self.bn2 = _conv(planes, planes, 3), nn.BatchNorm2d(planes)
+        else:
+            cout = planes * 4
+            self.conv1, self.bn1 = _conv(cin, planes, 1), nn.BatchNorm2d(planes)
+            self.conv2, self.bn2 = _conv(planes, planes, 3, stride), nn.BatchNorm2d(planes)
+            self.conv3, self.bn3 = _conv(planes, cout, 1), nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(cout))
+        self.out_channels = cout
+
+    def forward(self, x):
+        skip = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        if self.kind != 'basic':
+            y = self.bn3(self.conv3(self.relu(y)))
+        return self.relu(y + skip)
+
+
+def _build_backbone(model):
+    kind, depths = _ARCH[model]
+    mods = [nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+            nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2, padding=1)]
+    cin = 64
+    for planes, stride, depth in zip(_STAGE_PLANES, _STAGE_STRIDES, depths):
+        units = []
+        for i in range(depth):
+            u = ResidualUnit(kind, cin, planes, stride if i == 0 else 1)
+            cin = u.out_channels
+            units.append(u)
+        mods.append(nn.Sequential(*units))
+    return nn.Sequential(*mods), cin
+
+
+class VOSNet(nn.Module):
+    def __init__(self, model='resnet50'):
+        super().__init__()
+        self.model = model
+        if model == 'facebook':
+            raise NotImplementedError("model='facebook' needs torch.hub.load of a remote repository "
+                                      '(reference vos_net.py:30); not available offline')
+        if model not in ('resnet18', 'resnet50', 'resnet101'):
+            raise NotImplementedError(model)
+        self.backbone, cout = _build_backbone(model)
+        if model != 'resnet18':
+            self.adjust_dim = nn.Conv2d(cout, 256, kernel_size=1, stride=1, padding=0, bias=False)
+            self.bn256 = nn.BatchNorm2d(256)
+        self._init_weights()
+
+    def _init_weights(self):
+        # He-normal convolutions, unit BatchNorm (reference resnet.py:116-122); adjust_dim/bn256 keep torch defaults
+        for m in self.backbone.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                nn.init.normal_(m.weight, 0.0, (2.0 / n) ** 0.5)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        x = self.backbone(x)
+        if self.model != 'resnet18':
+            x = self.bn256(self.adjust_dim(x))
+        return x
+
+    def freeze_feature_extraction(self):
+        self.backbone.requires_grad_(False)
+
+    def prepare_for_inference(self, device, dtype=torch.bfloat16):
+        """eval + channels_last + reduced-precision weights on `device` (the reference runs the encoder under
+        torch.cuda.amp.autocast = fp16 on GPU, inference_utils.py:35,52)."""
+        self.eval().to(device)
+        if dtype is not None and dtype != torch.float32:
+            self.to(dtype)
+        return self.to(memory_format=torch.channels_last)

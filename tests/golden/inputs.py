@@ -137,3 +137,32 @@ def rollout_features(case):
 
 def onehot_indices(seed=5, n=40, d=5):
     return np.random.RandomState(seed).randint(0, d, size=n).astype(np.int64)
+
+
+# ---- encoder fixtures: deterministic weights keyed by parameter NAME (order independent) ----
+def fill_state_dict(sd, seed=301):
+    """Return {key: numpy array} for every entry of a VOSNet state dict: the same values whatever module
+    registration order the implementation uses."""
+    import zlib
+    out = {}
+    for key, val in sd.items():
+        shape = tuple(val.shape)
+        rs = np.random.RandomState((zlib.crc32(key.encode()) + seed) % (2 ** 31))
+        if key.endswith('num_batches_tracked'):
+            out[key] = np.zeros(shape, dtype=np.int64)
+        elif key.endswith('running_var'):
+            out[key] = rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif key.endswith('running_mean'):
+            out[key] = (rs.standard_normal(shape) * 0.1).astype(np.float32)
+        elif len(shape) == 1 and key.endswith('weight'):
+            out[key] = rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif len(shape) == 1:
+            out[key] = (rs.standard_normal(shape) * 0.1).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            out[key] = (rs.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+    return out
+
+
+def encoder_input(seed=302, H=64, W=96):
+    return np.random.RandomState(seed).standard_normal((1, 3, H, W)).astype(np.float32)

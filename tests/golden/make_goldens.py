@@ -155,6 +155,31 @@ def main():
     idx = torch.from_numpy(gin.onehot_indices())
     out['onehot'] = index_to_onehot(idx, 5).numpy()
 
+    # ---- encoder (src/model/vos_net.py:9-51 over src/model/backbone/resnet.py), built WITHOUT the network fetch:
+    # resnetXX(pretrained=False) + the same wrapping VOSNet.__init__ does (vos_net.py:18-23) ----
+    import json
+    import torch.nn as nn
+    from src.model.backbone import resnet as rresnet
+    from src.model.vos_net import VOSNet as RefVOSNet
+    enc_keys = {}
+    for name in ('resnet18', 'resnet50', 'resnet101'):
+        net = RefVOSNet.__new__(RefVOSNet)
+        nn.Module.__init__(net)
+        net.model = name
+        net.backbone = nn.Sequential(*list(getattr(rresnet, name)(pretrained=False).children())[0:8])
+        if name != 'resnet18':
+            net.adjust_dim = nn.Conv2d(1024, 256, kernel_size=1, stride=1, padding=0, bias=False)
+            net.bn256 = nn.BatchNorm2d(256)
+        sd = net.state_dict()
+        enc_keys[name] = {k: list(v.shape) for k, v in sd.items()}
+        if name != 'resnet101':
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in gin.fill_state_dict(sd).items()})
+            net.eval()
+            with torch.no_grad():
+                y = net(torch.from_numpy(gin.encoder_input()))
+            out[f'enc_{name}_out'] = y.numpy().astype(np.float32)
+    (HERE / 'encoder_keys.json').write_text(json.dumps(enc_keys, indent=0, sort_keys=True))
+
     np.savez_compressed(HERE / 'reference_goldens.npz', **out)
     tot = sum(v.nbytes for v in out.values())
     print(f'wrote {len(out)} arrays, {tot / 1e6:.2f} MB raw ->', HERE / 'reference_goldens.npz',

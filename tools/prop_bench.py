@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Kernel-only bench of the propagation step (no encoder): SURVEY.md section 8d's synthetic kernel inputs -
+features ~ N(0, 0.25^2) rounded to bf16 (logits ~ N(0,1)), uniform one-hot labels, frame_idx = 20 so both sigma
+branches are live.  Prints the mean kernel time from HIP events (vosprop_time_last_propagation).
+Used under rocprofv3 for the PMC passes."""
+import argparse
+import importlib
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--hd', type=int, default=60)
+    ap.add_argument('--wd', type=int, default=107)
+    ap.add_argument('--ref-num', type=int, default=9)
+    ap.add_argument('--d', type=int, default=4)
+    ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--scale', type=float, default=0.25)
+    ap.add_argument('--prob', action='store_true')
+    args = ap.parse_args()
+    vos = importlib.import_module('semi-supervised-vos_amd')
+    dev = torch.device('cuda', 0)
+    Hd, Wd, fi = args.hd, args.wd, 20
+    T = fi + 1
+    g = torch.Generator(device='cpu').manual_seed(0)
+    feats = (torch.randn(T, 256, Hd, Wd, generator=g) * args.scale).to(torch.bfloat16).to(dev)
+    lab = torch.randint(0, args.d, (T, Hd * Wd), generator=g)
+    oh = torch.zeros(args.d, T, Hd * Wd).scatter_(0, lab.unsqueeze(0), 1.0).to(dev)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=args.ref_num)
+    out = eng.predict(feats[:fi], feats[fi], oh[:, :fi], fi, 40, args.ref_num, 1.0, 8.0, 21.0, args.prob)
+    torch.cuda.synchronize()
+    us = eng.time_last_propagation(args.iters)
+    st = eng.last_stats()
+    print(json.dumps({'kernel_us': us, 'tflops': st['flops'] / us / 1e6, 'frac_of_2500': st['flops'] / us / 1e6 / 2500,
+                      'workgroups': st['workgroups'], 'tiles_per_wg': st['tiles_per_wg'], 'n_ref': st['n_ref'],
+                      'hw': st['hw'], 'checksum': float(out.sum())}))
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()
