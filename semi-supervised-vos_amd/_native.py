@@ -11,7 +11,7 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 _SRC = _PKG / 'csrc'
-LIB_PATH = _PKG / 'libvosprop.so'
+LIB_PATH = Path(os.environ['VOSPROP_LIB']) if os.environ.get('VOSPROP_LIB') else _PKG / 'libvosprop.so'   # override: dev ablation builds only
 _LIB = None
 
 

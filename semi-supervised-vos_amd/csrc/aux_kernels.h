@@ -85,25 +85,27 @@ __global__ void pack_f32_kernel(const float* __restrict__ L, size_t ld, int d, b
     if (lab_lo) *(bf16x8*)(lab_lo + (size_t)gid * 8) = ol;
 }
 
-// Merge the per-unit partials of one target pixel, normalise, arg-max.
+// Merge the partials of one target pixel, normalise, arg-max.
 //   out[k,t] = sum_u Y_u[k] 2^((m_u - M) c) / sum_u l_u 2^((m_u - M) c)      (reference predict.py:55-70)
 //   cls[t]   = argmax_k out[k,t], first maximum wins (reference inference_utils.py:70, torch.argmax on CPU)
-// grid = TT, block = 256 (one thread per target pixel of the tile).
-__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ part, int U, int d, int HW, float c,
+// The partial slots that hold target tile tt are listed in CSR form (plist_off[tt] .. plist_off[tt+1]); the host
+// derives them from the same WorkMap the propagation kernel uses.  grid = TT, block = 256 (one thread per pixel).
+__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ part, const int* __restrict__ plist_off,
+                                                      const int* __restrict__ plist, int d, int HW, float c,
                                                       float* __restrict__ pred, uint8_t* __restrict__ cls) {
     const int tt = blockIdx.x, col = threadIdx.x;
     const int t = tt * kBT + col;
     if (t >= HW) return;
     const size_t ustride = (size_t)(2 + d) * kBT;
-    const float* base = part + (size_t)tt * U * ustride + col;
+    const int u0 = plist_off[tt], u1 = plist_off[tt + 1];
     float M = -3.0e38f;
-    for (int u = 0; u < U; ++u) M = fmaxf(M, base[u * ustride]);
+    for (int u = u0; u < u1; ++u) M = fmaxf(M, part[(size_t)plist[u] * ustride + col]);
     float Lsum = 0.0f;
     float acc[kMaxClasses];
 #pragma unroll
     for (int k = 0; k < kMaxClasses; ++k) acc[k] = 0.0f;
-    for (int u = 0; u < U; ++u) {
-        const float* pu = base + u * ustride;
+    for (int u = u0; u < u1; ++u) {
+        const float* pu = part + (size_t)plist[u] * ustride + col;
         const float sc = __builtin_amdgcn_exp2f((pu[0] - M) * c);
         Lsum += pu[kBT] * sc;
 #pragma unroll

@@ -14,6 +14,7 @@ constexpr int kMaxClasses = 32;
 constexpr int kMaxRef = 64;
 constexpr int kCoordCh = 16;       // extra K channels that carry the spatial prior
 constexpr int kContinuousFrame = 4;   // reference src/config.py:13
+constexpr int kXcd = 8;            // XCDs: blocks b and b+8 share an L2 (placement is a speed matter only)
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -43,25 +44,49 @@ __host__ __device__ inline void split3(float x, float& h, float& m, float& l) {
     l = bf16_round(x - h - m);
 }
 
+// Work decomposition of one propagation ("stream-K" over reference tiles, XCD-partitioned):
+//   the N*tiles_per_frame reference steps are cut into kXcd contiguous parts; the workgroups with
+//   blockIdx % 8 == x walk part x for every target tile, so that part's features stay in that XCD's L2.
+//   Inside an XCD the (target tile, step) space of TT * |part| steps is cut evenly over `wg_per_xcd`
+//   workgroups, target-major, so a workgroup streams a contiguous run of reference tiles against one
+//   (rarely two or three) target tiles.  Both the kernel and combine_kernel evaluate this map.
+struct WorkMap {
+    int TT;           // target tiles (kBT pixels each)
+    int NT;           // reference steps = n_ref * tiles_per_frame
+    int wg_per_xcd;   // I
+    int max_parts;    // partial slots reserved per workgroup
+
+    __host__ __device__ inline void xcd_range(int x, int& r0, int& r1) const {
+        r0 = (int)((long long)x * NT / kXcd);
+        r1 = (int)((long long)(x + 1) * NT / kXcd);
+    }
+    // [q0, q1) of workgroup i in XCD x, in units of steps of the flattened (tt, step) space
+    __host__ __device__ inline void wg_range(int rx, int i, long long& q0, long long& q1) const {
+        const long long Q = (long long)TT * rx;
+        q0 = Q * i / wg_per_xcd;
+        q1 = Q * (i + 1) / wg_per_xcd;
+    }
+};
+
 // Per-launch description of one propagation (passed by value as a kernel argument).
 struct PropArgs {
     const bf16_t* feat_ring;    // [cap][HWp][kC]        pixel-major bf16 features
     const bf16_t* coord_tab;    // [HWp/32][2][32][8]    reference-side spatial channels
     const bf16_t* lab_hi;       // [cap][HWp/32][2][64][8] labels in MFMA A-operand order (hi part)
     const bf16_t* lab_lo;       // same, low part (probability mode) or nullptr
-    float* part;                // [TT][U][2+d][kBT]     per-unit partial (m, l, numerators)
+    float* part;                // [8*I][max_parts][2+d][kBT]  per-workgroup partial (m, l, numerators)
     int slot[kMaxRef];          // ring slot of each sampled reference frame
     unsigned long long sparse_mask;   // bit n set: frame n uses sigma2 (the "interval" frames)
+    WorkMap map;
     int target_slot;
     int n_ref;
     int HW, HWp, Wd;
     int d;
     int tiles_per_frame;        // HWp / 32
-    int row_splits;             // RS: workgroups per (target tile, frame)
-    int tiles_per_split;
     float c;                    // temperature * log2(e)
     double g1, g2;              // 1 / (sigma^2 * temperature) for sigma1, sigma2
     double two_over_w, gamma;   // 2/W_d, 1 + 1/W_d^2
+    unsigned long long* dbg;    // diagnostic builds only (-DVOSPROP_STAMP): per-wave cycle sums; else nullptr
 };
 
 }  // namespace vosprop

@@ -34,6 +34,15 @@ struct LastProp {
     bool prob = false, lab_lo = false;
 };
 
+// Device copy of the partial-slot lists of one work decomposition (depends only on TT, NT).
+struct Plan {
+    int NT = -1;
+    WorkMap map;
+    int n_parts = 0;          // total partial slots = grid * max_parts
+    int* d_off = nullptr;     // [TT + 1]
+    int* d_list = nullptr;    // slot indices, CSR by target tile
+};
+
 }  // namespace
 
 struct vosprop_ctx {
@@ -51,6 +60,7 @@ struct vosprop_ctx {
     int frame_idx = 0;
     int d = 0, H = 0, W = 0;
     LastProp last;
+    std::vector<Plan> plans;   // cache keyed by NT (n_ref * tiles)
     vosprop_stats stats;
     std::string err;
 };
@@ -125,19 +135,53 @@ int ensure_part(vosprop_ctx* ctx, size_t bytes) {
     return VOSPROP_OK;
 }
 
-// How many workgroups split one (target tile, reference frame): minimise rounds x tiles per workgroup.
-int plan_row_splits(int TT, int n_ref, int tiles) {
-    const int slots = 256;   // one 8-wave workgroup per CU
-    int best = 1;
-    long best_cost = -1;
-    for (int rs = 1; rs <= 8; ++rs) {
-        const long wgs = (long)TT * n_ref * rs;
-        const long rounds = (wgs + slots - 1) / slots;
-        const long per = (tiles + rs - 1) / rs + 4;   // +4 tiles ~ prologue/epilogue of a workgroup
-        const long cost = rounds * per;
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rs; }
+// Work decomposition for NT reference steps (see WorkMap in common.h) + the CSR list, per target tile, of the
+// partial slots that will hold it.  Cached per NT; built on first use (a few microseconds of host work).
+int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
+    for (const Plan& p : ctx->plans)
+        if (p.NT == NT) { *out = &p; return VOSPROP_OK; }
+    Plan p;
+    p.NT = NT;
+    p.map.TT = ctx->TT;
+    p.map.NT = NT;
+    long long per_xcd = ((long long)ctx->TT * NT + kXcd - 1) / kXcd;
+    long long I = per_xcd / 4;   // at least ~4 tile steps per workgroup
+    p.map.wg_per_xcd = (int)(I < 1 ? 1 : (I > 32 ? 32 : I));
+    p.map.max_parts = 1;
+    std::vector<std::vector<int>> lists((size_t)ctx->TT);
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int x = 0; x < kXcd; ++x) {
+            int r0, r1;
+            p.map.xcd_range(x, r0, r1);
+            const int RX = r1 - r0;
+            if (RX <= 0) continue;
+            for (int i = 0; i < p.map.wg_per_xcd; ++i) {
+                long long q0, q1;
+                p.map.wg_range(RX, i, q0, q1);
+                if (q1 <= q0) continue;
+                const int tf = (int)(q0 / RX), tl = (int)((q1 - 1) / RX);
+                if (pass == 0) {
+                    if (tl - tf + 1 > p.map.max_parts) p.map.max_parts = tl - tf + 1;
+                } else {
+                    const int b = i * kXcd + x;
+                    for (int tt = tf; tt <= tl; ++tt) lists[(size_t)tt].push_back(b * p.map.max_parts + (tt - tf));
+                }
+            }
+        }
     }
-    return best;
+    std::vector<int> off((size_t)ctx->TT + 1, 0), flat;
+    for (int tt = 0; tt < ctx->TT; ++tt) {
+        off[(size_t)tt + 1] = off[(size_t)tt] + (int)lists[(size_t)tt].size();
+        flat.insert(flat.end(), lists[(size_t)tt].begin(), lists[(size_t)tt].end());
+    }
+    p.n_parts = kXcd * p.map.wg_per_xcd * p.map.max_parts;
+    HIP_TRY(ctx, hipMalloc((void**)&p.d_off, off.size() * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc((void**)&p.d_list, (flat.size() + 1) * sizeof(int)));
+    HIP_TRY(ctx, hipMemcpy(p.d_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(p.d_list, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+    ctx->plans.push_back(p);
+    *out = &ctx->plans.back();
+    return VOSPROP_OK;
 }
 
 template <typename T>
@@ -194,24 +238,29 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.Wd = ctx->cfg.feat_w;
     a.d = d;
     a.tiles_per_frame = ctx->tiles;
-    a.row_splits = plan_row_splits(ctx->TT, n_ref, ctx->tiles);
-    a.tiles_per_split = (ctx->tiles + a.row_splits - 1) / a.row_splits;
+    const Plan* plan = nullptr;
+    int rc = get_plan(ctx, n_ref * ctx->tiles, &plan);
+    if (rc) return rc;
+    a.map = plan->map;
     a.c = (float)((double)temperature * 1.4426950408889634);
     a.g1 = 1.0 / ((double)sigma1 * sigma1 * temperature);
     a.g2 = 1.0 / ((double)sigma2 * sigma2 * temperature);
     a.two_over_w = 2.0 / ctx->cfg.feat_w;
     a.gamma = 1.0 + 1.0 / ((double)ctx->cfg.feat_w * ctx->cfg.feat_w);
-    const int U = n_ref * a.row_splits;
-    lp.grid = ctx->TT * U;
+    lp.grid = kXcd * plan->map.wg_per_xcd;
     lp.prob = prob;
     lp.lab_lo = lab_lo;
-    int rc = ensure_part(ctx, (size_t)lp.grid * (2 + d) * kBT * sizeof(float));
+    rc = ensure_part(ctx, (size_t)plan->n_parts * (2 + d) * kBT * sizeof(float));
     if (rc) return rc;
     a.part = ctx->part;
     launch_prop(lp, s);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(combine_kernel, dim3(ctx->TT), dim3(kBT), 0, s, ctx->part, U, d, ctx->HW, a.c, pred, cls);
+    hipLaunchKernelGGL(combine_kernel, dim3(ctx->TT), dim3(kBT), 0, s, ctx->part, plan->d_off, plan->d_list, d, ctx->HW,
+                       a.c, pred, cls);
     HIP_TRY(ctx, hipGetLastError());
+#ifdef VOSPROP_STAMP
+    lp.args.dbg = nullptr;   // set by vosprop_debug_stamps
+#endif
     lp.valid = true;
     ctx->last = lp;
     vosprop_stats& st = ctx->stats;
@@ -219,7 +268,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     st.n_ref = n_ref;
     st.hw = ctx->HW;
     st.workgroups = lp.grid;
-    st.tiles_per_wg = a.tiles_per_split;
+    st.tiles_per_wg = (int)(((long long)ctx->TT * n_ref * ctx->tiles + lp.grid - 1) / lp.grid);
     st.flops = 2.0 * n_ref * HW * HW * kC + 2.0 * d * n_ref * HW * HW;
     st.bytes = n_ref * HW * kC * 2.0 + HW * kC * 2.0 + n_ref * HW + d * HW * 4.0;
     return VOSPROP_OK;
@@ -340,6 +389,10 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     ring_free(ctx->scratch);
     if (ctx->coord_tab) (void)hipFree(ctx->coord_tab);
     if (ctx->part) (void)hipFree(ctx->part);
+    for (Plan& p : ctx->plans) {
+        if (p.d_off) (void)hipFree(p.d_off);
+        if (p.d_list) (void)hipFree(p.d_list);
+    }
     if (ctx->pred_buf) (void)hipFree(ctx->pred_buf);
     if (ctx->cls_tmp) (void)hipFree(ctx->cls_tmp);
     delete ctx;
@@ -483,5 +536,25 @@ int vosprop_time_last_propagation(vosprop_ctx* ctx, int iters, void* stream, dou
     *mean_us = (double)ms * 1000.0 / iters;
     return VOSPROP_OK;
 }
+
+#ifdef VOSPROP_STAMP
+// Diagnostic builds only (not part of include/vosprop.h): re-run the last propagation with in-kernel s_memtime stamps and
+// return, per wave, the cycle sums of the VOSPROP_NSTAMP loop segments.  out_host: [grid*8*VOSPROP_NSTAMP] u64.
+int vosprop_debug_stamps(vosprop_ctx* ctx, unsigned long long* out_host, int max_words) {
+    if (!ctx || !ctx->last.valid) return VOSPROP_E_STATE;
+    const size_t n = (size_t)ctx->last.grid * kWaves * VOSPROP_NSTAMP;
+    if ((size_t)max_words < n) return VOSPROP_E_INVALID;
+    unsigned long long* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, n * 8));
+    HIP_TRY(ctx, hipMemset(d, 0, n * 8));
+    LastProp lp = ctx->last;
+    lp.args.dbg = d;
+    launch_prop(lp, nullptr);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(out_host, d, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return (int)n;
+}
+#endif
 
 }  // extern "C"

@@ -14,219 +14,472 @@
 //   * numerators  out[k,t] = sum_r L[k,r] a[r,t]  are a second MFMA: the weighted probabilities a (already
 //     laid out rows-in-registers / column-on-lane) are packed to bf16 and used as the B operand against the
 //     label matrix stored in HBM in A-operand order.  Denominators stay f32 on the VALU.
-//   * one workgroup = 8 waves x 32 target pixels = 256 target pixels (B fragments live in registers for the
-//     whole kernel); reference tiles (32 pixels x 512 B, XOR-swizzled) stream through a double-buffered LDS.
-//   * partial (m, l, numerators) per (target tile, reference chunk) go to HBM; combine_kernel merges them.
+//   * one workgroup = 8 waves x 32 target pixels = 256 target pixels (B fragments live in registers);
+//     reference tiles (32 pixels x 512 B in 528-B padded rows: conflict-free ds_read_b128 at immediate
+//     offsets) stream through a 3-deep LDS ring, one barrier per tile.
+//   * waves 4-7 run half a tile behind waves 0-3: while one wave of a SIMD is in its MFMA burst the other is in
+//     its softmax (VALU/transcendental) burst, so the matrix pipe and the vector issue overlap.
+//   * persistent stream-K grid (WorkMap in common.h): every CU gets the same number of tiles; the reference
+//     stream is partitioned over the 8 XCDs so each L2 keeps 1/8 of the features.
+//   * partial (m, l, numerators) per (workgroup, target tile) go to HBM; combine_kernel merges them.
 #pragma once
 #include "common.h"
 
+#ifdef VOSPROP_STAMP
+#define VOSPROP_NSTAMP 12
+// diagnostic build: STAMP_AT(k) adds the cycles since the previous stamp to bucket k (wave-uniform scalars)
+#define STAMP_DECL unsigned long long tsum[VOSPROP_NSTAMP] = {}; unsigned long long tprev = 0
+#define STAMP_ARGS , unsigned long long (&tsum)[VOSPROP_NSTAMP], unsigned long long& tprev
+#define STAMP_PASS , tsum, tprev
+#define STAMP_AT(k)                                                                        \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long tn_;                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_)::"memory");      \
+        tsum[k] += tn_ - tprev;                                                            \
+        tprev = tn_;                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_ARGS
+#define STAMP_PASS
+#define STAMP_AT(k) __builtin_amdgcn_sched_barrier(0)
+#endif
+
+#ifndef VOSPROP_ABLATE
+#define VOSPROP_ABLATE 0   // timing experiments only (tools/ablate.sh): 1 = no exp, 2 = no score MFMAs, 4 = no staging, 8 = no barriers, 16 = stage one cached tile
+#endif
+
 namespace vosprop {
 
-constexpr int kLdsFeat = kTileR * kC * 2;        // 16384
-constexpr int kLdsCoord = 2 * 32 * 16;           // 1024
-constexpr int kLdsLab = 2 * 64 * 16;             // 2048
-constexpr int kLdsBuf = kLdsFeat + kLdsCoord + 2 * kLdsLab;   // 21504
-constexpr float kRescaleThr = 8.0f;              // defer-max threshold in log2 units (p <= 2^8)
+constexpr int kRowB = kC * 2 + 16;                // 528: padded LDS row
+constexpr int kLdsFeat = 17 * 1024;               // 32 rows x 528 B = 16896, rounded up to whole 1-KiB LDS-DMA pieces
+constexpr int kLdsCoord = 2 * 32 * 16;            // 1024
+constexpr int kLdsLab = 2 * 64 * 16;              // 2048
+constexpr int kOffCoord = kLdsFeat;
+constexpr int kOffLabHi = kLdsFeat + kLdsCoord;
+constexpr int kOffLabLo = kOffLabHi + kLdsLab;
+constexpr int kLdsBuf = kOffLabLo + kLdsLab;      // 22528
+constexpr int kRing = 3;
+constexpr int kGlbFeat = kTileR * kC * 2;         // 16384 bytes of one tile in HBM
+constexpr float kRescaleThr = 8.0f;               // defer-max threshold in log2 units (p <= 2^8)
 constexpr float kNegBig = -1.0e30f;
 
-__device__ __forceinline__ float other_half(float x) {
-    // value held by lane ^ 32
-    return __shfl_xor(x, 32);
+__device__ __forceinline__ float half_max(float x) {   // max(x[lane], x[lane ^ 32]) in every lane
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {   // x[lane] + x[lane ^ 32]
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+struct ColState {
+    float m;     // running max of raw S of this column (shared by both half-waves)
+    float l;     // partial denominator over this half-wave's rows: sum 2^((S - m) c)
+    f32x16 Y;    // numerators: rows = classes, column = this lane's target pixel
+};
+
+// Label fragments (MFMA A operand) of one tile.
+template <bool LAB_LO>
+struct LabFrag {
+    bf16x8 h0, h1, l0, l1;
+    __device__ __forceinline__ void load(const unsigned char* lb, int lane) {
+        const unsigned char* lh = lb + kOffLabHi + lane * 16;
+        h0 = *(const bf16x8*)(lh);
+        h1 = *(const bf16x8*)(lh + 1024);
+        if (LAB_LO) {
+            l0 = *(const bf16x8*)(lh + kLdsLab);
+            l1 = *(const bf16x8*)(lh + kLdsLab + 1024);
+        }
+    }
+};
+
+// A-operand fragments of a tile that are fetched ahead of its MFMA chain: channels 0..127 (8 x ds_read_b128)
+// and the 16 spatial channels.
+template <bool PROB>
+struct AFrag {
+    bf16x8 a[8];
+    bf16x8 ax;
+    // two halves so that the second one can be issued after the softmax has released its registers
+    __device__ __forceinline__ void prefetch_lo(const unsigned char* lb, int j, int h) {
+        const unsigned char* arow = lb + j * kRowB + h * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a[ks] = *(const bf16x8*)(arow + ks * 32);
+        if (!PROB) ax = *(const bf16x8*)(lb + kOffCoord + h * 512 + j * 16);
+    }
+    __device__ __forceinline__ void prefetch_hi(const unsigned char* lb, int j, int h) {
+        const unsigned char* arow = lb + j * kRowB + h * 16;
+#pragma unroll
+        for (int ks = 4; ks < 8; ++ks) a[ks] = *(const bf16x8*)(arow + ks * 32);
+    }
+    __device__ __forceinline__ void prefetch(const unsigned char* lb, int j, int h) {
+        prefetch_lo(lb, j, h);
+        prefetch_hi(lb, j, h);
+    }
+};
+
+// 16 + 1 MFMAs: S = R.T over the 256 channels, Sw = S + spatial term.  The first 8 fragments were prefetched during the
+// previous softmax burst; each MFMA is followed by the ds_read_b128 (immediate offset) that refills its slot with the
+// fragment 8 steps ahead, so the chain never waits on LDS.
+template <bool PROB>
+__device__ __forceinline__ void tile_scores(const unsigned char* lb, int j, int h, const bf16x8 (&Bt)[16],
+                                            const bf16x8& Bx, AFrag<PROB>& f, f32x16& S, f32x16& Sw) {
+    const unsigned char* arow = lb + j * kRowB + h * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#if VOSPROP_ABLATE & 2
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        asm volatile("" ::"v"(f.a[ks]), "v"(Bt[ks]));
+        f.a[ks] = *(const bf16x8*)(arow + (ks + 8) * 32);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" ::"v"(f.a[ks]), "v"(Bt[ks + 8]));
+    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], Bt[0], S, 0, 0, 0);
+#else
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks], Bt[ks], S, 0, 0, 0);
+        f.a[ks] = *(const bf16x8*)(arow + (ks + 8) * 32);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks], Bt[ks + 8], S, 0, 0, 0);
+#endif
+    if (!PROB) Sw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ax, Bx, S, 0, 0, 0);
+}
+
+// Online softmax update of one 32x32 score tile + label product.
+template <bool PROB, bool LAB_LO>
+__device__ __forceinline__ void tile_softmax(const LabFrag<LAB_LO>& lab, int h, f32x16& S, f32x16& Sw, ColState& st,
+                                             float c, float kq, bool tail, int rows_valid STAMP_ARGS) {
+    if (tail) {
+        // padded reference rows of a frame's last tile must not enter the softmax (wave-uniform, rare)
+        asm volatile("; tail tile" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (acc_row(r, h) >= rows_valid) {
+                S[r] = kNegBig;
+                if (!PROB) Sw[r] = kNegBig;
+            }
+        }
+    }
+    // Optimistic pass: exponentiate against the CURRENT running max; the running max is only raised (and this tile
+    // redone) when some score exceeds it by more than kRescaleThr - rare after the first tiles - so the max reduction is
+    // off the critical path: a depth-3 v_max3 tree that the scheduler interleaves with the exps.
+    float mc = st.m * c;
+    float mq = mc + kq;
+    float e[16], p[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e[r] = __builtin_fmaf(S[r], c, -mc);
+    float t0, t1, t2, t3, t4, emax;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(e[0]), "v"(e[1]), "v"(e[2]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(e[3]), "v"(e[4]), "v"(e[5]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t2) : "v"(e[6]), "v"(e[7]), "v"(e[8]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(e[9]), "v"(e[10]), "v"(e[11]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t4) : "v"(e[12]), "v"(e[13]), "v"(e[14]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(t0), "v"(t1), "v"(t2));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(t3), "v"(t4), "v"(e[15]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(emax) : "v"(t0), "v"(t3));
+    float l0 = 0.0f, l1 = 0.0f;   // two chains: halves the dependent-add latency
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+#if VOSPROP_ABLATE & 1
+        const float pa = e[r], pb = e[r + 1];
+        p[r] = PROB ? pa : __builtin_fmaf(Sw[r], c, -mq);
+        p[r + 1] = PROB ? pb : __builtin_fmaf(Sw[r + 1], c, -mq);
+#else
+        const float pa = __builtin_amdgcn_exp2f(e[r]);
+        const float pb = __builtin_amdgcn_exp2f(e[r + 1]);
+        p[r] = PROB ? pa : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r], c, -mq));
+        p[r + 1] = PROB ? pb : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r + 1], c, -mq));
+#endif
+        l0 += pa;
+        l1 += pb;
+    }
+    if (__any(emax > kRescaleThr)) {
+        // slow path: raise the running max (shared by the two half-waves of a column), rescale what was accumulated
+        // against the old one exactly once, and redo this tile against the new one (cdna guide T13 hazard)
+        asm volatile("; rescale" ::: "memory");
+        float u0, u1, u2, u3, u4, smax;   // max raw score of this column in this tile (from S itself: e loses it when
+                                          // the running max is still the -1e30 start value)
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u0) : "v"(S[0]), "v"(S[1]), "v"(S[2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u1) : "v"(S[3]), "v"(S[4]), "v"(S[5]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u2) : "v"(S[6]), "v"(S[7]), "v"(S[8]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u3) : "v"(S[9]), "v"(S[10]), "v"(S[11]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u4) : "v"(S[12]), "v"(S[13]), "v"(S[14]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u0) : "v"(u0), "v"(u1), "v"(u2));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u3) : "v"(u3), "v"(u4), "v"(S[15]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(smax) : "v"(u0), "v"(u3));
+        const float tmax = half_max(smax);
+        const float mn = fmaxf(st.m, tmax);
+        const float sc = __builtin_amdgcn_exp2f((st.m - mn) * c);
+        st.l *= sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.Y[r] *= sc;
+        st.m = mn;
+        mc = mn * c;
+        mq = mc + kq;
+        l0 = 0.0f;
+        l1 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], c, -mc));
+            const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], c, -mc));
+            p[r] = PROB ? pa : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r], c, -mq));
+            p[r + 1] = PROB ? pb : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r + 1], c, -mq));
+            l0 += pa;
+            l1 += pb;
+        }
+    }
+    st.l += l0 + l1;
+#ifdef VOSPROP_STAMP
+    STAMP_AT(6);
+#endif
+    bf16x8 pk0, pk1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        pk0[e] = (bf16_t)p[e];
+        pk1[e] = (bf16_t)p[8 + e];
+    }
+    st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.h0, pk0, st.Y, 0, 0, 0);
+    st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.h1, pk1, st.Y, 0, 0, 0);
+    if (LAB_LO) {
+        st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.l0, pk0, st.Y, 0, 0, 0);
+        st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.l1, pk1, st.Y, 0, 0, 0);
+    }
 }
 
 template <bool PROB, bool LAB_LO>
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArgs A) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kLdsBuf];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kRing * kLdsBuf];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31;     // MFMA row (A operand) / column (B operand, C/D)
-    const int h = lane >> 5;     // k-half of the operand fragments / row-half of the accumulator
+#ifndef VOSPROP_GROUP_MODE
+#define VOSPROP_GROUP_MODE 0
+#endif
+    // the half-tile-late wave group (experiments: 1 = odd waves, 2 = waves 2,3,6,7, 3 = no skew)
+    const bool grpB = VOSPROP_GROUP_MODE == 0 ? wave >= 4 : VOSPROP_GROUP_MODE == 1 ? (wave & 1) != 0
+                      : VOSPROP_GROUP_MODE == 2 ? ((wave >> 1) & 1) != 0 : false;
+    const int j = lane & 31;       // MFMA row (A operand) / column (B operand, C/D)
+    const int h = lane >> 5;       // k-half of the operand fragments / row-half of the accumulator
 
-    const int U = A.n_ref * A.row_splits;
-    const int tt = blockIdx.x / U;
-    const int u = blockIdx.x - tt * U;
-    const int n = u / A.row_splits;
-    const int rs = u - n * A.row_splits;
-    const int tile_begin = rs * A.tiles_per_split;
-    int tile_end = tile_begin + A.tiles_per_split;
-    if (tile_end > A.tiles_per_frame) tile_end = A.tiles_per_frame;
-
-    const int slot = A.slot[n];
-    const bool sparse = (A.sparse_mask >> n) & 1ull;
-    const size_t frame_tiles = (size_t)slot * A.tiles_per_frame;
-    const unsigned char* feat_base = (const unsigned char*)(A.feat_ring + (size_t)slot * A.HWp * kC);
-    const unsigned char* coord_base = (const unsigned char*)A.coord_tab;
-    const unsigned char* labhi_base = (const unsigned char*)A.lab_hi + frame_tiles * kLdsLab;
-    const unsigned char* lablo_base = LAB_LO ? (const unsigned char*)A.lab_lo + frame_tiles * kLdsLab : nullptr;
-
-    // ---- target (B operand) fragments: 32 columns x 256 channels per wave, resident in registers ----
-    int t = tt * kBT + wave * kColsPerWave + j;
-    const int t_ld = t < A.HWp ? t : A.HWp - 1;
-    const bf16_t* trow = A.feat_ring + ((size_t)A.target_slot * A.HWp + t_ld) * kC + h * 8;
-    bf16x8 Bt[16];
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) Bt[ks] = *(const bf16x8*)(trow + ks * 16);
-
-    // ---- target-side spatial channels (one fragment for this chunk's sigma) and the per-column constant ----
-    bf16x8 Bx;
-    float kq = 0.0f;   // g * Q_t * c
-    if (!PROB) {
-        const double g = sparse ? A.g2 : A.g1;
-        const int tq = t < A.HW ? t : A.HW - 1;
-        const double at = (double)(tq / A.Wd), bt = (double)(tq % A.Wd);
-        const double tw = A.two_over_w, gm = A.gamma;
-        const float alpha = (float)(g * (2.0 * at + tw * bt));
-        const float beta = (float)(g * (2.0 * gm * bt + tw * at));
-        const float kappa = (float)(-g);
-        kq = (float)(g * (at * at + tw * at * bt + gm * bt * bt) * (double)A.c);
-        float ah, am, al, bh, bm, bl, kh, km, kl;
-        split3(alpha, ah, am, al);
-        split3(beta, bh, bm, bl);
-        split3(kappa, kh, km, kl);
-        // channels 0-7 (k-half 0): alpha x3, beta x3, kappa_h, kappa_m ; channels 8-15 (k-half 1): kappa_l, kappa_h,
-        // kappa_m, kappa_h, 0...  (pairs with the reference-side table built by build_coord_table)
-        Bx[0] = (bf16_t)(h ? kl : ah);
-        Bx[1] = (bf16_t)(h ? kh : am);
-        Bx[2] = (bf16_t)(h ? km : al);
-        Bx[3] = (bf16_t)(h ? kh : bh);
-        Bx[4] = (bf16_t)(h ? 0.0f : bm);
-        Bx[5] = (bf16_t)(h ? 0.0f : bl);
-        Bx[6] = (bf16_t)(h ? 0.0f : kh);
-        Bx[7] = (bf16_t)(h ? 0.0f : km);
-    }
-
-    // ---- staging: global -> registers -> LDS (XOR-swizzled feature rows) ----
-    uint4 g0, g1, g2;
-    const int q0 = tid, q1 = tid + 512;
-    const int row0 = q0 >> 5, ch0 = q0 & 31, row1 = q1 >> 5, ch1 = q1 & 31;
-    const int dst0 = row0 * 512 + ((ch0 ^ (row0 & 15)) << 4);
-    const int dst1 = row1 * 512 + ((ch1 ^ (row1 & 15)) << 4);
-    // waves 0: coord (64 chunks), 1-2: label hi (128 chunks), 3-4: label lo (128 chunks)
-    const int aux_kind = wave == 0 ? 0 : (wave <= 2 ? 1 : (wave <= 4 ? 2 : 3));
-    const int aux_idx = aux_kind == 0 ? tid : (aux_kind == 1 ? tid - 64 : tid - 192);
-    const int aux_dst = (aux_kind == 0 ? kLdsFeat : (aux_kind == 1 ? kLdsFeat + kLdsCoord : kLdsFeat + kLdsCoord + kLdsLab))
-                        + aux_idx * 16;
-
-    auto stage_load = [&](int tile) {
-        const unsigned char* f = feat_base + (size_t)tile * kLdsFeat;
-        g0 = *(const uint4*)(f + q0 * 16);
-        g1 = *(const uint4*)(f + q1 * 16);
-        if (aux_kind == 0) {
-            if (!PROB) g2 = *(const uint4*)(coord_base + (size_t)tile * kLdsCoord + aux_idx * 16);
-        } else if (aux_kind == 1) {
-            g2 = *(const uint4*)(labhi_base + (size_t)tile * kLdsLab + aux_idx * 16);
-        } else if (aux_kind == 2) {
-            if (LAB_LO) g2 = *(const uint4*)(lablo_base + (size_t)tile * kLdsLab + aux_idx * 16);
-        }
-    };
-    auto stage_write = [&](int buf) {
-        unsigned char* b = smem + buf * kLdsBuf;
-        *(uint4*)(b + dst0) = g0;
-        *(uint4*)(b + dst1) = g1;
-        if ((aux_kind == 0 && !PROB) || aux_kind == 1 || (aux_kind == 2 && LAB_LO)) *(uint4*)(b + aux_dst) = g2;
-    };
-
-    // ---- running statistics (per lane: its column, its half's rows) ----
-    float m = kNegBig;   // running max of raw S (shared by both halves of a column)
-    float l = 0.0f;      // partial denominator: sum over this half's rows of 2^((S - m) c)
-    f32x16 Y;            // numerators: rows = classes, col = this lane's column
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Y[r] = 0.0f;
+    // ---- this workgroup's share of the (target tile, reference step) space ----
+    const int x = blockIdx.x & (kXcd - 1), wi = blockIdx.x >> 3;
+    int rx0, rx1;
+    A.map.xcd_range(x, rx0, rx1);
+    const int RX = rx1 - rx0;
+    if (RX <= 0) return;
+    long long q0, q1;
+    A.map.wg_range(RX, wi, q0, q1);
+    if (q1 <= q0) return;
+    const int tt_first = (int)(q0 / RX);
+    const int TPF = A.tiles_per_frame;
     const float c = A.c;
+    const bool ragged = A.HW != A.HWp;
+    const int rows_last = A.HW - (TPF - 1) * kTileR;   // valid rows of a frame's last tile
 
-    if (tile_begin < tile_end) {
-        stage_load(tile_begin);
-        stage_write(0);
-    }
-    __syncthreads();
+    // ---- staging roles (LDS-DMA, global_load_lds_dwordx4: one wave instruction lands 1 KiB = 64 lanes x 16 B at a
+    // wave-uniform LDS address, the SOURCE address is per lane).  A tile is 17 feature pieces (the 528-B padded row image is
+    // produced by the per-lane source offsets: LDS unit q of 16 B holds chunk q % 33 of row q / 33, chunk 32 = padding),
+    // 1 coordinate piece, 2 + 2 label pieces.  Wave w issues feature pieces w and w + 8, and one more: wave 0 feature
+    // piece 16, wave 1 coordinates, waves 2-3 label hi, waves 4-5 label lo.
+    auto feat_src_off = [&](int piece) -> unsigned {
+        int qq = 64 * piece + lane;
+        if (qq >= kTileR * 33) qq = 0;   // lanes past the image (piece 16, lanes 32-63): any valid source, lands in slack
+        int row = qq / 33, ch = qq - row * 33;
+        if (ch == 32) ch = 31;
+        return (unsigned)(row * 512 + ch * 16);
+    };
+    const unsigned src_a = feat_src_off(wave), src_b = feat_src_off(wave + 8), src_c = feat_src_off(16);
+    long long q = q0;
+    while (q < q1) {
+        // ---- one segment: a run of reference steps against ONE target tile ----
+        const int tt = (int)(q / RX);
+        const int r_lo = rx0 + (int)(q - (long long)tt * RX);
+        long long q_end = (long long)(tt + 1) * RX;
+        if (q_end > q1) q_end = q1;
+        const int n_steps = (int)(q_end - q);
+        q = q_end;
 
-    int buf = 0;
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const bool has_next = tile + 1 < tile_end;
-        if (has_next) stage_load(tile + 1);
-
-        const unsigned char* lb = smem + buf * kLdsBuf;
-        const unsigned char* arow = lb + j * 512;
-        f32x16 S;
+        // target (B operand) fragments: 32 columns x 256 channels per wave, resident in registers
+        const int t = tt * kBT + wave * kColsPerWave + j;
+        const int t_ld = t < A.HWp ? t : A.HWp - 1;
+        const bf16_t* trow = A.feat_ring + ((size_t)A.target_slot * A.HWp + t_ld) * kC + h * 8;
+        bf16x8 Bt[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const bf16x8 a = *(const bf16x8*)(arow + (((2 * ks + h) ^ (j & 15)) << 4));
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Bt[ks], S, 0, 0, 0);
-        }
-        f32x16 Sw;
+        for (int ks = 0; ks < 16; ++ks) Bt[ks] = *(const bf16x8*)(trow + ks * 16);
+
+        // target-side spatial channels for both sigmas and the per-column constants g*Q_t*c
+        bf16x8 Bx1, Bx2;
+        float kq1 = 0.0f, kq2 = 0.0f;
         if (!PROB) {
-            const bf16x8 ax = *(const bf16x8*)(lb + kLdsFeat + h * 512 + j * 16);
-            Sw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, Bx, S, 0, 0, 0);
-        }
-        // padded reference rows of the frame's last tile must not enter the softmax
-        if (tile == A.tiles_per_frame - 1 && A.HW != A.HWp) {
-            const int r0 = tile * kTileR;
+            const int tq = t < A.HW ? t : A.HW - 1;
+            const double at = (double)(tq / A.Wd), bt = (double)(tq % A.Wd);
+            const double tw = A.two_over_w, gm = A.gamma;
+            const double qt = at * at + tw * at * bt + gm * bt * bt;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (r0 + acc_row(r, h) >= A.HW) {
-                    S[r] = kNegBig;
-                    if (!PROB) Sw[r] = kNegBig;
-                }
+            for (int sg = 0; sg < 2; ++sg) {
+                const double g = sg ? A.g2 : A.g1;
+                float ah, am, al, bh, bm, bl, kh, km, kl;
+                split3((float)(g * (2.0 * at + tw * bt)), ah, am, al);
+                split3((float)(g * (2.0 * gm * bt + tw * at)), bh, bm, bl);
+                split3((float)(-g), kh, km, kl);
+                // channels 0-7 (k-half 0): alpha x3, beta x3, kappa_h, kappa_m; channels 8-15 (k-half 1): kappa_l,
+                // kappa_h, kappa_m, kappa_h, 0...  (pairs with the reference-side table of build_coord_table)
+                bf16x8 B;
+                B[0] = (bf16_t)(h ? kl : ah);
+                B[1] = (bf16_t)(h ? kh : am);
+                B[2] = (bf16_t)(h ? km : al);
+                B[3] = (bf16_t)(h ? kh : bh);
+                B[4] = (bf16_t)(h ? 0.0f : bm);
+                B[5] = (bf16_t)(h ? 0.0f : bl);
+                B[6] = (bf16_t)(h ? 0.0f : kh);
+                B[7] = (bf16_t)(h ? 0.0f : km);
+                if (sg) { Bx2 = B; kq2 = (float)(g * qt * (double)c); }
+                else { Bx1 = B; kq1 = (float)(g * qt * (double)c); }
             }
         }
 
-        // ---- online softmax: tile max, deferred rescale ----
-        float tmax = S[0];
+        asm volatile("" : "+v"(kq1), "+v"(kq2));   // keep the f64 derivation out of the tile loop
+
+        ColState st;
+        st.m = kNegBig;
+        st.l = 0.0f;
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
-        tmax = fmaxf(tmax, other_half(tmax));
-        if (__any((tmax - m) * c > kRescaleThr)) {
-            const float mn = fmaxf(m, tmax);
-            const float sc = __builtin_amdgcn_exp2f((m - mn) * c);
-            l *= sc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Y[r] *= sc;
-            m = mn;
+        for (int r = 0; r < 16; ++r) st.Y[r] = 0.0f;
+
+        // Every thread runs the SAME stream, one step per reference tile p:
+        //     scores(p): fetch tile p+2 (HBM -> registers); label fragments of p; 17 MFMAs            | barrier
+        //     softmax(p): prefetch the first fragments of tile p+1; exp / sums / label MFMAs; stage p+2 | barrier
+        // Group B runs one barrier late, so in every barrier interval one wave of a SIMD is in its MFMA burst and the
+        // other in its softmax burst.  Tile t sits in ring slot t % 3: written during step t-2, read during steps t-1
+        // (prefetch) and t.
+        unsigned f_off = 0;          // byte offset of the staging cursor's tile inside its frame
+        int sn = 0, stile = 0;       // staging cursor (frame, tile-in-frame)
+        const unsigned char *f_base = nullptr, *lh_base = nullptr, *ll_base = nullptr;
+        auto stage_frame = [&]() {   // per-frame bases (wave-uniform; a scalar load per FRAME, not per tile)
+            const int slot = A.slot[sn];
+            f_base = (const unsigned char*)A.feat_ring + (size_t)slot * A.HWp * kC * 2;
+            lh_base = (const unsigned char*)A.lab_hi + (size_t)slot * TPF * kLdsLab;
+            if (LAB_LO) ll_base = (const unsigned char*)A.lab_lo + (size_t)slot * TPF * kLdsLab;
+        };
+        auto stage_seek = [&](int step) {
+            sn = (r_lo + step) / TPF;
+            stile = (r_lo + step) - sn * TPF;
+            stage_frame();
+        };
+        auto stage_issue = [&](int buf) {   // fetch the staging cursor's tile straight into ring slot `buf`
+            typedef __attribute__((address_space(3))) void* lds_ptr;
+            typedef const __attribute__((address_space(1))) void* glb_ptr;
+            unsigned char* lds = smem + buf * kLdsBuf;
+            const unsigned char* f = f_base + (size_t)stile * kGlbFeat;
+            __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_a), (lds_ptr)(lds + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_b), (lds_ptr)(lds + (wave + 8) * 1024), 16, 0, 0);
+            if (wave == 0) {
+                __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_c), (lds_ptr)(lds + 16 * 1024), 16, 0, 0);
+            } else if (wave == 1) {
+                if (!PROB)
+                    __builtin_amdgcn_global_load_lds((glb_ptr)((const unsigned char*)A.coord_tab + (size_t)stile * kLdsCoord + lane * 16),
+                                                     (lds_ptr)(lds + kOffCoord), 16, 0, 0);
+            } else if (wave <= 3) {
+                __builtin_amdgcn_global_load_lds((glb_ptr)(lh_base + (size_t)stile * kLdsLab + (wave - 2) * 1024 + lane * 16),
+                                                 (lds_ptr)(lds + kOffLabHi + (wave - 2) * 1024), 16, 0, 0);
+            } else if (wave <= 5) {
+                if (LAB_LO)
+                    __builtin_amdgcn_global_load_lds((glb_ptr)(ll_base + (size_t)stile * kLdsLab + (wave - 4) * 1024 + lane * 16),
+                                                     (lds_ptr)(lds + kOffLabLo + (wave - 4) * 1024), 16, 0, 0);
+            }
+            if (++stile == TPF) {
+                asm volatile("; next staged frame" ::: "memory");
+                stile = 0;
+                ++sn;
+                if (sn < A.n_ref) stage_frame();
+            }
+        };
+        auto stage_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        (void)f_off;
+
+        // prologue: tiles 0 and 1 by everyone
+        stage_seek(0);
+        stage_issue(0);
+        if (n_steps > 1) stage_issue(1);
+        stage_wait();
+        __syncthreads();
+        if (grpB) __syncthreads();
+
+        STAMP_DECL;
+#ifdef VOSPROP_STAMP
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
+        // compute cursor + the per-frame operands of the tile being scored
+        int cn = r_lo / TPF, ctile = r_lo - cn * TPF;
+        bool sparse = (A.sparse_mask >> cn) & 1ull;
+        float kq = sparse ? kq2 : kq1;
+
+        AFrag<PROB> fr;
+        fr.prefetch(smem, j, h);
+        int b_cur = 0, b_nxt = 1, b_st = 2;
+        for (int p = 0; p < n_steps; ++p) {
+            const bool have_st = (VOSPROP_ABLATE & 4) ? false : (p + 2 < n_steps);
+            const unsigned char* lb = smem + b_cur * kLdsBuf;
+            STAMP_AT(0);   // bucket 0: loop overhead (+ time between segments)
+            // ---- scores(p) ----
+            if (have_st) stage_issue(b_st);
+            LabFrag<LAB_LO> lab;
+            lab.load(lb, lane);
+            STAMP_AT(1);   // 1: issue of the LDS-DMA pieces + label reads
+            f32x16 S, Sw;
+            tile_scores<PROB>(lb, j, h, Bt, sparse ? Bx2 : Bx1, fr, S, Sw);
+            STAMP_AT(2);   // 2: MFMA chain
+            if (!(VOSPROP_ABLATE & 8)) __syncthreads();
+            STAMP_AT(3);   // 3: barrier 1
+            // ---- softmax(p) ----
+            fr.prefetch_lo(smem + b_nxt * kLdsBuf, j, h);   // first fragments of tile p+1 (harmless when p+1 == n_steps)
+            STAMP_AT(4);   // 4: prefetch issue   (5: max + rescale decision, 6: exps + sums inside tile_softmax)
+            const bool tail = ragged && ctile == TPF - 1;
+            tile_softmax<PROB, LAB_LO>(lab, h, S, Sw, st, c, kq, tail, rows_last STAMP_PASS);
+            STAMP_AT(7);   // 7: pack + label MFMAs
+            fr.prefetch_hi(smem + b_nxt * kLdsBuf, j, h);
+            stage_wait();   // this wave's pieces of tile p+2 have landed (issued a whole step ago)
+            if (++ctile == TPF) {   // the next tile starts a new reference frame: its sigma may differ
+                asm volatile("; next scored frame" ::: "memory");
+                ctile = 0;
+                ++cn;
+                sparse = (A.sparse_mask >> cn) & 1ull;
+                kq = sparse ? kq2 : kq1;
+            }
+            STAMP_AT(8);   // 8: DMA wait + frame bookkeeping
+            if (!(VOSPROP_ABLATE & 8)) __syncthreads();
+            STAMP_AT(9);   // 9: barrier 2
+            const int tmp = b_cur;
+            b_cur = b_nxt;
+            b_nxt = b_st;
+            b_st = tmp;
         }
-        const float mc = m * c;
-        const float mq = mc + kq;
-        float p[16];
+        if (!grpB) __syncthreads();
+#ifdef VOSPROP_STAMP
+        if (A.dbg && lane == 0)
+            for (int k = 0; k < VOSPROP_NSTAMP; ++k)
+                atomicAdd(&A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + k], tsum[k]);
+#endif
+
+        // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
+        const float lsum = half_sum(st.l);
+        float* part = A.part + (((size_t)blockIdx.x * A.map.max_parts + (tt - tt_first)) * (2 + A.d)) * kBT
+                      + wave * kColsPerWave + j;
+        if (h == 0) {
+            part[0] = st.m;
+            part[kBT] = lsum;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], c, -mc));
-            l += pe;
-            p[r] = PROB ? pe : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r], c, -mq));
+            const int cls = acc_row(r, h);
+            if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
         }
-        bf16x8 pk0, pk1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            pk0[e] = (bf16_t)p[e];
-            pk1[e] = (bf16_t)p[8 + e];
-        }
-        // ---- numerators: Y[class, t] += L[class, rows] . a[rows, t] ----
-        const unsigned char* lh = lb + kLdsFeat + kLdsCoord + lane * 16;
-        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lh), pk0, Y, 0, 0, 0);
-        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lh + 1024), pk1, Y, 0, 0, 0);
-        if (LAB_LO) {
-            Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lh + kLdsLab), pk0, Y, 0, 0, 0);
-            Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lh + kLdsLab + 1024), pk1, Y, 0, 0, 0);
-        }
-
-        if (has_next) stage_write(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-
-    // ---- write this unit's partial: rows (m, l, numerators[d]) x 256 columns ----
-    const float lsum = l + other_half(l);
-    float* part = A.part + ((size_t)blockIdx.x * (2 + A.d)) * kBT + wave * kColsPerWave + j;
-    if (h == 0) {
-        part[0] = m;
-        part[kBT] = lsum;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int cls = acc_row(r, h);
-        if (cls < A.d) part[(size_t)(2 + cls) * kBT] = Y[r];
     }
 }
 

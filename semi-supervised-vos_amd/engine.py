@@ -94,6 +94,8 @@ class PropagationEngine:
     def step(self, features, want_pred=True, want_mask=True):
         """features: (C,H_d,W_d) or (1,C,H_d,W_d) tensor on this engine's GPU (f32 / f16 / bf16).
         Frame 0 returns (None, None); later frames return (prediction (d,HW) f32 | None, mask (H,W) u8 | None)."""
+        if self.frame_index < 0:
+            raise VospropError('step() before begin_video()')
         f = features[0] if features.dim() == 4 else features
         if f.device != self.device:
             raise VospropError(f'features live on {f.device}, engine on {self.device}')

@@ -40,6 +40,22 @@ def main():
     print(json.dumps({'kernel_us': us, 'tflops': st['flops'] / us / 1e6, 'frac_of_2500': st['flops'] / us / 1e6 / 2500,
                       'workgroups': st['workgroups'], 'tiles_per_wg': st['tiles_per_wg'], 'n_ref': st['n_ref'],
                       'hw': st['hw'], 'checksum': float(out.sum())}))
+    L = vos._native.lib()
+    if hasattr(L, 'vosprop_debug_stamps'):     # -DVOSPROP_STAMP diagnostic build
+        import ctypes
+        import numpy as np
+        NS = 12
+        n = st['workgroups'] * 8 * NS
+        buf = np.zeros(n, dtype=np.uint64)
+        L.vosprop_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        got = L.vosprop_debug_stamps(eng._ctx, buf.ctypes.data_as(ctypes.c_void_p), n)
+        assert got == n, got
+        a = buf.reshape(-1, 8, NS).astype(np.float64) / st['tiles_per_wg']
+        names = ['loop', 'ld-issue', 'mfma', 'bar1', 'prefetch', 'max', 'exp', 'labmfma', 'stwrite', 'bar2']
+        print('stamps: cycles per tile')
+        for g, sl in (('A (waves 0-3)', slice(0, 4)), ('B (waves 4-7)', slice(4, 8))):
+            m = a[:, sl].mean((0, 1))
+            print(f'  group {g}: ' + ' '.join(f'{nm}={v:.0f}' for nm, v in zip(names, m)) + f'  total={m.sum():.0f}')
     eng.close()
 
 
