@@ -6,6 +6,7 @@ operator interface.  No CPU fallback exists: without libvosprop.so / a HIP devic
 from . import _native
 from ._native import VospropError, build
 from .engine import PropagationEngine, feature_map_size, sample_frames_list, PREC_BF16, PREC_F32
+from .config import Config
 
-__all__ = ['PropagationEngine', 'VospropError', 'build', 'feature_map_size', 'sample_frames_list',
+__all__ = ['Config', 'PropagationEngine', 'VospropError', 'build', 'feature_map_size', 'sample_frames_list',
            'PREC_BF16', 'PREC_F32']

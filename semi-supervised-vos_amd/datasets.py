@@ -1,0 +1,52 @@
+"""Input contract of the reference's InferenceDataset (src/utils/datasets.py:111-167) without torchvision:
+sorted video directories, sorted frames, JPEG -> RGB -> [0,1] CHW f32 -> ImageNet normalisation.
+Items are (tensor (3,H,W), video_name); the DataLoader's batch of 1 turns that into ((1,3,H,W), (name,))."""
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.utils.data
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+_EXT = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.pgm', '.tif', '.tiff', '.webp')
+
+
+def list_videos(root):
+    """{video_name: [frame paths]} in the order torchvision's ImageFolder walks them (sorted dirs, sorted files)."""
+    root = Path(root)
+    out = {}
+    for vdir in sorted(p for p in root.iterdir() if p.is_dir()):
+        frames = sorted(f for f in vdir.rglob('*') if f.is_file() and f.suffix.lower() in _EXT)
+        if frames:
+            out[vdir.name] = frames
+    return out
+
+
+def normalize_image(img):
+    """PIL image -> (3,H,W) f32, ToTensor + Normalize (datasets.py:128-131,147)."""
+    a = np.asarray(img.convert('RGB'), dtype=np.float32) / 255.0
+    a = (a - np.asarray(IMAGENET_MEAN, np.float32)) / np.asarray(IMAGENET_STD, np.float32)
+    return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+
+
+class InferenceDataset(torch.utils.data.Dataset):
+    def __init__(self, root, transform=None, target_transform=None, disable=False, inference_strategy='single',
+                 scale=None, videos=None):
+        if inference_strategy != 'single':
+            raise NotImplementedError(f"inference strategy '{inference_strategy}' is not built (SURVEY.md section 8f)")
+        vids = list_videos(root)
+        if videos is not None:           # a shard: subset of the video names, reference order kept
+            vids = {k: v for k, v in vids.items() if k in set(videos)}
+        self.videos = vids
+        self.imgs = [(p, name) for name, frames in vids.items() for p in frames]
+        self.img_bytes = [Path(p).read_bytes() for p, _ in self.imgs]   # preloaded, as the reference does (:133-135)
+
+    def __getitem__(self, index):
+        from io import BytesIO
+        from PIL import Image
+        img = Image.open(BytesIO(self.img_bytes[index]))
+        return normalize_image(img), self.imgs[index][1]
+
+    def __len__(self):
+        return len(self.imgs)

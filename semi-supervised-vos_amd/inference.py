@@ -1,0 +1,120 @@
+"""`main.py inference` with the reference's flags (src/inference.py:18-113) plus --gpus / --encoder-dtype.
+
+--gpus N > 1 starts one process per GPU; whole videos are dealt longest-first to the GPUs (sharding.py); there is no
+collective on the data path, only a host-side sum of {frames, seconds} for the fps line."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import click
+import torch
+import torch.utils.data
+
+from .config import Config
+from .datasets import InferenceDataset, list_videos
+from .inference_utils import inference_single
+from .sharding import shard_for_rank
+from .utils import load_model
+from .vos_net import VOSNet
+
+_DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
+
+
+@click.command(name='inference')
+@click.option('--ref_num', '-n', type=int, default=9, help='Number of reference frames for inference.')
+@click.option('--data', '-d', type=click.Path(file_okay=False, dir_okay=True), required=True,
+              help='Path to inference dataset folder.')
+@click.option('--resume', '-r', type=click.Path(file_okay=True, dir_okay=False), required=True,
+              help='Path to the trained checkpoint.')
+@click.option('--model', '-m', type=click.Choice(['resnet18', 'resnet50', 'resnet101', 'facebook']), default='resnet50',
+              help='Network architecture, resnet18, resnet50, resnet101 or facebook.')
+@click.option('--temperature', '-t', type=float, default=1.0, help='Temperature parameter.')
+@click.option('--frame_range', type=int, default=40, help='Range of frames for inference.')
+@click.option('--sigma_1', type=float, default=8.0, help='Smaller sigma in the motion model for dense spatial weight')
+@click.option('--sigma_2', type=float, default=21.0, help='Larger sigma in the motion model for dense spatial weight.')
+@click.option('--save', '-s', type=click.Path(file_okay=False, dir_okay=True), required=True,
+              help='Path to save predictions.')
+@click.option('--device', type=click.Choice(['cpu', 'cuda']), default='cuda', help='Device to run computing on.')
+@click.option('--inference-strategy',
+              type=click.Choice(['single', 'hor-flip', 'vert-flip', '2-scale', 'multimodel', 'hor-2-scale', '3-scale']),
+              default='single', help='Inference strategy.')
+@click.option('--additional-model', type=click.Path(file_okay=True, dir_okay=False), required=False,
+              help='Path to the additional checkpoint.')
+@click.option('--additional-model-type', type=click.STRING, required=False, default='resnet50',
+              help='Type of additional model type.')
+@click.option('--probability/--no-probability', default=False, required=False,
+              help='Should probability or labels be propagated.')
+@click.option('--scale', default=1.15, required=False, type=click.FLOAT, help='Scale for 2nd image in 2-scale strategy.')
+@click.option('--fusion', default='mean', type=click.Choice(['maximum', 'minimum', 'mean']),
+              help='Fusion operation for probability propagation.')
+@click.option('--gpus', type=int, default=1, help='[engine] GPUs of this node to shard the videos over.')
+@click.option('--encoder-dtype', type=click.Choice(sorted(_DTYPES)), default='bf16',
+              help='[engine] encoder precision (the reference runs it under fp16 autocast on GPU).')
+@click.option('--shard', type=(int, int), default=(0, 1), hidden=True, help='[engine] internal: rank, world')
+def inference_command(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
+                      inference_strategy, additional_model, additional_model_type, probability, scale, fusion, gpus,
+                      encoder_dtype, shard):
+    if gpus > 1 and shard == (0, 1):
+        return _launch_shards(gpus)
+    inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
+                           inference_strategy, additional_model, additional_model_type, probability, scale, fusion,
+                           encoder_dtype=encoder_dtype, shard=shard)
+
+
+def _launch_shards(gpus):
+    """One child process per GPU (HIP_VISIBLE_DEVICES pins it); children never exec after touching the GPU."""
+    argv = [a for a in sys.argv[1:]]
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(r), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, sys.argv[0]] + argv + ['--shard', str(r), str(gpus)], env=env,
+                                      stdout=subprocess.PIPE, text=True))
+    frames, secs, rc = 0, 0.0, 0
+    for p in procs:
+        out, _ = p.communicate()
+        rc |= p.returncode
+        for line in out.splitlines():
+            if line.startswith('{"vosprop_stats"'):
+                st = json.loads(line)['vosprop_stats']
+                frames += st['frames']
+                secs = max(secs, st['seconds'])
+    print(json.dumps({'gpus': gpus, 'frames': frames, 'seconds': secs, 'frames_per_s': frames / secs if secs else 0.0}))
+    if rc:
+        raise SystemExit(rc)
+
+
+def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
+                           inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
+                           reduction, disable=False, encoder_dtype='bf16', shard=(0, 1)):
+    if inference_strategy != 'single':
+        raise NotImplementedError(f"inference strategy '{inference_strategy}' is not built yet (SURVEY.md section 8f); "
+                                  "'single' is the path this engine replaces")
+    if Config.DEVICE.type != device:
+        Config.DEVICE = torch.device(device)
+    if Config.DEVICE.type == 'cuda':
+        Config.DEVICE = torch.device('cuda', torch.cuda.current_device())
+    net = VOSNet(model=model)
+    net = load_model(net, resume)
+    dtype = _DTYPES[encoder_dtype] if Config.DEVICE.type == 'cuda' else None
+    net.prepare_for_inference(Config.DEVICE, dtype)
+
+    data_dir = str(Path(data) / 'JPEGImages/480p')
+    videos = None
+    if shard[1] > 1:
+        lengths = {k: len(v) for k, v in list_videos(data_dir).items()}
+        videos = shard_for_rank(lengths, shard[0], shard[1])
+    dataset = InferenceDataset(data_dir, disable=disable, inference_strategy=inference_strategy, scale=scale, videos=videos)
+    loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1)
+    annotation_dir = Path(data) / 'Annotations/480p'
+    if len(dataset) == 0:
+        print(json.dumps({'vosprop_stats': {'frames': 0, 'videos': 0, 'seconds': 0.0, 'shard': list(shard)}}))
+        return
+    last_video = dataset.imgs[0][1]
+    stats = {}
+    with torch.no_grad():
+        inference_single(net, loader, len(dataset), annotation_dir, last_video, save, sigma_1, sigma_2, frame_range,
+                         ref_num, temperature, probability_propagation, disable, encoder_dtype=dtype, stats=stats)
+    stats['shard'] = list(shard)
+    print(json.dumps({'vosprop_stats': stats}))

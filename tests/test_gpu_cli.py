@@ -1,0 +1,67 @@
+"""End to end on the GPU: `main.py inference` over a tiny synthetic DAVIS-layout dataset, checked against the oracle."""
+import importlib
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from oracle import vos_oracle as vo
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _make_dataset(root, n_frames=12, H=96, W=160):
+    from PIL import Image
+    case = dict(gin.ROLLOUT_CASES[0], image_hw=(H, W))
+    ann = gin.rollout_annotation(case)
+    frames = {}
+    for vid, seed in (('bear', 1), ('camel', 2)):
+        (root / 'JPEGImages' / '480p' / vid).mkdir(parents=True)
+        (root / 'Annotations' / '480p' / vid).mkdir(parents=True)
+        rs = np.random.RandomState(seed)
+        base = rs.randint(0, 255, (H // 8, W // 8, 3)).astype(np.float32)
+        imgs = []
+        for i in range(n_frames):
+            base = np.clip(base + rs.randn(*base.shape) * 6, 0, 255)
+            img = np.asarray(Image.fromarray(base.astype(np.uint8)).resize((W, H), Image.BILINEAR))
+            Image.fromarray(img).save(root / 'JPEGImages' / '480p' / vid / f'{i:05d}.png')   # lossless, so the oracle sees the same pixels
+            imgs.append(img)
+        frames[vid] = imgs
+        im = Image.fromarray(ann, mode='P')
+        im.putpalette(gin.DAVIS_PALETTE + [0] * (768 - 24))
+        im.save(root / 'Annotations' / '480p' / vid / '00000.png')
+    return ann, frames
+
+
+def test_inference_cli_matches_oracle(tmp_path):
+    from PIL import Image
+    vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
+    ds = importlib.import_module('semi-supervised-vos_amd.datasets')
+    ann, frames = _make_dataset(tmp_path / 'data')
+    torch.manual_seed(0)
+    net = vn.VOSNet('resnet18')
+    ckpt = tmp_path / 'ckpt.pth.tar'
+    torch.save({'state_dict': net.state_dict()}, ckpt)
+    out = subprocess.run([sys.executable, 'main.py', 'inference', '-d', str(tmp_path / 'data'), '-r', str(ckpt), '-m',
+                          'resnet18', '-s', str(tmp_path / 'out'), '--encoder-dtype', 'f32', '--ref_num', '5',
+                          '--frame_range', '6'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    stats = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"vosprop_stats"')][0])['vosprop_stats']
+    assert stats['frames'] == 24 and stats['videos'] == 2
+    net.eval().cuda()
+    for vid, imgs in frames.items():
+        with torch.no_grad():
+            feats = torch.cat([net(ds.normalize_image(Image.fromarray(im))[None].cuda()) for im in imgs]).cpu().numpy()
+        _, want = vo.rollout(ann, feats, 6, 5, 1.0, 8.0, 21.0, False)
+        first = Image.open(tmp_path / 'out' / vid / '00000.png')
+        assert first.mode == 'P' and np.array_equal(np.asarray(first), ann)
+        got = np.stack([np.asarray(Image.open(tmp_path / 'out' / vid / f'{i:05d}.png')) for i in range(1, len(imgs))])
+        assert Image.open(tmp_path / 'out' / vid / '00001.png').mode == 'P'
+        assert np.mean(got != want) <= 0.01, f'{vid}: {np.mean(got != want) * 100:.2f} % of pixels differ'
+        assert min(vo.mask_iou_per_object(want, got, int(ann.max()) + 1)) >= 0.97

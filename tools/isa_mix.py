@@ -13,7 +13,7 @@ blocks = []
 cur = 'entry'
 for ln in s[start:end].split('\n'):
     t = ln.strip()
-    if re.match(r'^\.LBB\d+_\d+:', t):
+    if re.match(r'^\.LBB\d+_\d+:', t) or re.match(r'^; %bb\.\d+:', t):
         blocks.append((cur, cnt))
         cur = t
         cnt = collections.Counter()
