@@ -96,6 +96,8 @@ def main():
     ap.add_argument('--encoder-dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--prime', type=int, default=20, help='untimed frames that fill the reference history')
+    ap.add_argument('--encoder-batch', type=int, default=16,
+                    help='frames encoded per encoder call (features do not depend on the propagated labels)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -131,9 +133,22 @@ def main():
 
     keep_feats, keep_cls = [], []
 
+    B = max(1, args.encoder_batch)
+    feat_buf = {'f': None, 'pos': 0}
+
+    def encode_next(i):
+        """Encoder look-ahead: the features of frames i .. i+B-1 in one call; the propagation stays strictly sequential."""
+        if feat_buf['f'] is None or feat_buf['pos'] == B:
+            idx = torch.arange(i, i + B, device=dev) % pool
+            with torch.no_grad():
+                feat_buf['f'] = net(clip.index_select(0, idx).contiguous(memory_format=torch.channels_last))
+            feat_buf['pos'] = 0
+        f = feat_buf['f'][feat_buf['pos']]
+        feat_buf['pos'] += 1
+        return f
+
     def one_frame(i, keep=False):
-        with torch.no_grad():
-            feats = net(clip[i % pool:i % pool + 1])
+        feats = encode_next(i)[None]
         pred, mask = eng.step(feats, want_pred=keep, want_mask=True)
         if keep:
             keep_feats.append(feats.float().cpu())
@@ -147,6 +162,7 @@ def main():
     for _ in range(args.warmup):
         one_frame(fi)
         fi += 1
+    feat_buf['f'] = None   # the timed region starts with an empty look-ahead buffer: it pays for every frame it uses
 
     def fence():
         torch.cuda.synchronize()
@@ -171,7 +187,8 @@ def main():
     prop_us = eng.time_last_propagation(iters=50)
     achieved = st['flops'] / (prop_us * 1e-6) / 1e12
     # propagation-only frames/s (push + propagate + combine + label pack + mask), encoder excluded
-    feats = net(clip[0:1]).detach()
+    with torch.no_grad():
+        feats = net(clip[0:1]).detach()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(50):
@@ -187,7 +204,7 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'image': [H, W], 'feature_map': [Hd, Wd], 'ref_num': wl['ref_num'],
                        'frame_range': cfg['frame_range'], 'topk': wl['topk'], 'encoder': wl['model'],
-                       'encoder_dtype': args.encoder_dtype, 'encoder_weights': 'random-init', 'objects': 3,
+                       'encoder_dtype': args.encoder_dtype, 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
             'propagation_only_frames_per_s_per_gpu': prop_fps,
             'roofline': {'kernel': 'prop_bf16_kernel', 'bound': 'mfma', 'achieved': achieved,

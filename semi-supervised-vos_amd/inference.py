@@ -52,15 +52,16 @@ _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
 @click.option('--gpus', type=int, default=1, help='[engine] GPUs of this node to shard the videos over.')
 @click.option('--encoder-dtype', type=click.Choice(sorted(_DTYPES)), default='bf16',
               help='[engine] encoder precision (the reference runs it under fp16 autocast on GPU).')
+@click.option('--encoder-batch', type=int, default=16, help='[engine] frames per encoder call (look-ahead).')
 @click.option('--shard', type=(int, int), default=(0, 1), hidden=True, help='[engine] internal: rank, world')
 def inference_command(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                       inference_strategy, additional_model, additional_model_type, probability, scale, fusion, gpus,
-                      encoder_dtype, shard):
+                      encoder_dtype, encoder_batch, shard):
     if gpus > 1 and shard == (0, 1):
         return _launch_shards(gpus)
     inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_model, additional_model_type, probability, scale, fusion,
-                           encoder_dtype=encoder_dtype, shard=shard)
+                           encoder_dtype=encoder_dtype, shard=shard, encoder_batch=encoder_batch)
 
 
 def _launch_shards(gpus):
@@ -87,7 +88,7 @@ def _launch_shards(gpus):
 
 def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
-                           reduction, disable=False, encoder_dtype='bf16', shard=(0, 1)):
+                           reduction, disable=False, encoder_dtype='bf16', shard=(0, 1), encoder_batch=16):
     if inference_strategy != 'single':
         raise NotImplementedError(f"inference strategy '{inference_strategy}' is not built yet (SURVEY.md section 8f); "
                                   "'single' is the path this engine replaces")
@@ -115,6 +116,7 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
     stats = {}
     with torch.no_grad():
         inference_single(net, loader, len(dataset), annotation_dir, last_video, save, sigma_1, sigma_2, frame_range,
-                         ref_num, temperature, probability_propagation, disable, encoder_dtype=dtype, stats=stats)
+                         ref_num, temperature, probability_propagation, disable, encoder_dtype=dtype, stats=stats,
+                         encoder_batch=encoder_batch)
     stats['shard'] = list(shard)
     print(json.dumps({'vosprop_stats': stats}))

@@ -20,9 +20,35 @@ def _read_annotation(path):
     return np.asarray(ann), ann.getpalette(), ann
 
 
+def encoded_frames(model, loader, device, encoder_dtype, batch):
+    """Encoder look-ahead: yields (features (1,C,H_d,W_d), video_name) in loader order, but runs the encoder on up to `batch`
+    consecutive frames of one video at a time - the features do not depend on the propagated labels (only the labels are
+    sequential), and the encoder is ~3.5x cheaper per frame at batch 16 than at batch 1 on MI355X."""
+    pend, names = [], []
+
+    def flush():
+        x = torch.cat(pend).to(device, non_blocking=True)
+        if encoder_dtype is not None:
+            x = x.to(encoder_dtype)
+        with torch.no_grad():
+            f = model(x.contiguous(memory_format=torch.channels_last))
+        out = [(f[i:i + 1], names[i]) for i in range(len(names))]
+        pend.clear()
+        names.clear()
+        return out
+
+    for input, (name,) in loader:
+        if names and (name != names[-1] or len(names) == batch or input.shape != pend[-1].shape):
+            yield from flush()
+        pend.append(input)
+        names.append(name)
+    if names:
+        yield from flush()
+
+
 def inference_single(model, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                      frame_range, ref_num, temperature, probability_propagation, disable, encoder_dtype=None,
-                     stats=None):
+                     stats=None, encoder_batch=16):
     """stats (optional dict) receives {'frames', 'videos', 'seconds'} for the fps report."""
     import time
     from tqdm import tqdm
@@ -42,15 +68,11 @@ def inference_single(model, inference_loader, total_len, annotation_dir, last_vi
             save_predictions(torch.stack(masks).cpu().numpy(), palette, save, video)
             masks.clear()
 
-    for input, (current_video,) in tqdm(inference_loader, total=total_len, disable=disable):
+    stream = encoded_frames(model, inference_loader, device, encoder_dtype, max(1, encoder_batch))
+    for features, current_video in tqdm(stream, total=total_len, disable=disable):
         if current_video != last_video:
             flush(last_video)
             frame_idx = 0
-        input = input.to(device, non_blocking=True)
-        if encoder_dtype is not None:
-            input = input.to(encoder_dtype).contiguous(memory_format=torch.channels_last)
-        with torch.no_grad():
-            features = model(input)
         if frame_idx == 0:
             label, palette, ann_img = _read_annotation(Path(annotation_dir) / current_video / '00000.png')
             H_d, W_d = features.shape[-2:]

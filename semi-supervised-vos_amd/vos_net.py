@@ -111,10 +111,40 @@ class VOSNet(nn.Module):
     def freeze_feature_extraction(self):
         self.backbone.requires_grad_(False)
 
-    def prepare_for_inference(self, device, dtype=torch.bfloat16):
-        """eval + channels_last + reduced-precision weights on `device` (the reference runs the encoder under
-        torch.cuda.amp.autocast = fp16 on GPU, inference_utils.py:35,52)."""
+    def fold_batchnorm(self):
+        """Inference-only: fold every eval-mode BatchNorm into the convolution in front of it (w' = w * g/sqrt(v+eps),
+        b' = beta - mu * g/sqrt(v+eps), folded in f32) and replace it by Identity.  Removes ~50 element-wise launches per
+        frame; outputs are equal up to f32 rounding.  Call after the checkpoint is loaded."""
+        def fold(conv, bn):
+            w = conv.weight.detach().float()
+            scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+            fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                              conv.dilation, conv.groups, bias=True)
+            fused.weight.data = (w * scale.view(-1, 1, 1, 1)).to(conv.weight.dtype)
+            b0 = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(scale)
+            fused.bias.data = (bn.bias.detach().float() + (b0 - bn.running_mean.detach().float()) * scale).to(conv.weight.dtype)
+            return fused.to(conv.weight.device)
+
+        bb = self.backbone
+        bb[0], bb[1] = fold(bb[0], bb[1]), nn.Identity()
+        for stage in list(bb)[4:]:
+            for u in stage:
+                u.conv1, u.bn1 = fold(u.conv1, u.bn1), nn.Identity()
+                u.conv2, u.bn2 = fold(u.conv2, u.bn2), nn.Identity()
+                if u.kind != 'basic':
+                    u.conv3, u.bn3 = fold(u.conv3, u.bn3), nn.Identity()
+                if u.downsample is not None:
+                    u.downsample = nn.Sequential(fold(u.downsample[0], u.downsample[1]), nn.Identity())
+        if self.model != 'resnet18':
+            self.adjust_dim, self.bn256 = fold(self.adjust_dim, self.bn256), nn.Identity()
+        return self
+
+    def prepare_for_inference(self, device, dtype=torch.bfloat16, fold_bn=True):
+        """eval + folded BatchNorm + channels_last + reduced-precision weights on `device` (the reference runs the
+        encoder under torch.cuda.amp.autocast = fp16 on GPU, inference_utils.py:35,52)."""
         self.eval().to(device)
+        if fold_bn:
+            self.fold_batchnorm()
         if dtype is not None and dtype != torch.float32:
             self.to(dtype)
         return self.to(memory_format=torch.channels_last)

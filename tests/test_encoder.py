@@ -41,3 +41,16 @@ def test_forward_matches_reference(vos_net, goldens, name):
 def test_facebook_is_a_clear_error(vos_net):
     with pytest.raises(NotImplementedError):
         vos_net.VOSNet('facebook')
+
+
+@pytest.mark.parametrize('name', ['resnet18', 'resnet50'])
+def test_folded_batchnorm_is_equivalent(vos_net, name):
+    net = vos_net.VOSNet(name)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in gin.fill_state_dict(net.state_dict()).items()})
+    net.eval()
+    x = torch.from_numpy(gin.encoder_input())
+    with torch.no_grad():
+        y0 = net(x)
+        y1 = net.fold_batchnorm()(x)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules())
+    assert (y0 - y1).abs().max() <= 1e-4 * y0.abs().max()
