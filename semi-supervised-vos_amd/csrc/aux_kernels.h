@@ -13,34 +13,33 @@ template <> __device__ inline float to_f32<bf16_t>(bf16_t v) { return (float)v; 
 
 // Replaces reference src/model/predict.py:47 (permute(0,2,3,1).reshape) + the history append
 // (src/utils/inference_utils.py:72): (C, HW) channel-major -> ring slot [HWp][C] pixel-major bf16.
-// grid = ceil(HW/64), block = 256.  Rows >= HW of the slot stay zero (set once at allocation).
+// grid = (ceil(HW/64), C/64), block = 256: one 64-pixel x 64-channel tile per block, transposed through LDS so that both
+// the reads (256 B runs along pixels) and the writes (16 B per lane along channels) are coalesced.
+// Rows >= HW of the slot stay zero (set once at allocation).
 template <typename T>
 __global__ __launch_bounds__(256) void push_kernel(const T* __restrict__ src, bf16_t* __restrict__ dst, int HW) {
     __shared__ float tile[64][65];
-    const int p0 = blockIdx.x * 64;
+    const int p0 = blockIdx.x * 64, cc = blockIdx.y * 64;
     const int tid = threadIdx.x;
-    for (int cc = 0; cc < kC; cc += 64) {
-        const int p = tid & 63;
+    const int p = tid & 63;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ch = i * 4 + (tid >> 6);
-            float v = 0.0f;
-            if (p0 + p < HW) v = to_f32<T>(src[(size_t)(cc + ch) * HW + p0 + p]);
-            tile[ch][p] = v;
+    for (int i = 0; i < 16; ++i) {
+        const int ch = i * 4 + (tid >> 6);
+        float v = 0.0f;
+        if (p0 + p < HW) v = to_f32<T>(src[(size_t)(cc + ch) * HW + p0 + p]);
+        tile[ch][p] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int px = pass * 32 + (tid >> 3);
+        const int c8 = (tid & 7) * 8;
+        if (p0 + px < HW) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)tile[c8 + e][px];
+            *(bf16x8*)(dst + (size_t)(p0 + px) * kC + cc + c8) = o;
         }
-        __syncthreads();
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int px = pass * 32 + (tid >> 3);
-            const int c8 = (tid & 7) * 8;
-            if (p0 + px < HW) {
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (bf16_t)tile[c8 + e][px];
-                *(bf16x8*)(dst + (size_t)(p0 + px) * kC + cc + c8) = o;
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -85,45 +84,89 @@ __global__ void pack_f32_kernel(const float* __restrict__ L, size_t ld, int d, b
     if (lab_lo) *(bf16x8*)(lab_lo + (size_t)gid * 8) = ol;
 }
 
-// Merge the partials of one target pixel, normalise, arg-max.
+// Merge the partials of target pixels, normalise, arg-max, and write the new frame's labels in MFMA operand order.
 //   out[k,t] = sum_u Y_u[k] 2^((m_u - M) c) / sum_u l_u 2^((m_u - M) c)      (reference predict.py:55-70)
 //   cls[t]   = argmax_k out[k,t], first maximum wins (reference inference_utils.py:70, torch.argmax on CPU)
-// The partial slots that hold target tile tt are listed in CSR form (plist_off[tt] .. plist_off[tt+1]); the host
-// derives them from the same WorkMap the propagation kernel uses.  grid = TT, block = 256 (one thread per pixel).
+//   new label of the frame = one-hot(cls) or out itself in probability mode   (inference_utils.py:67-71)
+// The partial slots that hold target tile tt are listed in CSR form (plist_off[tt] .. plist_off[tt+1]); the host derives
+// them from the same WorkMap the propagation kernel uses.
+// grid = ceil(HW/64), block = 256 = 64 target pixels x 4 partial lanes (each lane folds every 4th partial with its own
+// running max; the 4 lanes are merged through LDS), then the block's two 32-pixel label tiles are packed (256 chunks).
 __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ part, const int* __restrict__ plist_off,
                                                       const int* __restrict__ plist, int d, int HW, float c,
-                                                      float* __restrict__ pred, uint8_t* __restrict__ cls) {
-    const int tt = blockIdx.x, col = threadIdx.x;
-    const int t = tt * kBT + col;
-    if (t >= HW) return;
+                                                      float* __restrict__ pred, uint8_t* __restrict__ cls,
+                                                      bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, int prob) {
+    __shared__ float red[4][kMaxClasses + 2][64];
+    __shared__ float outv[kMaxClasses][64];
+    __shared__ uint8_t clsv[64];
+    const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
+    const int t = blockIdx.x * 64 + col;
+    const int tt = (blockIdx.x * 64) / kBT, tcol = (blockIdx.x * 64) % kBT + col;
     const size_t ustride = (size_t)(2 + d) * kBT;
     const int u0 = plist_off[tt], u1 = plist_off[tt + 1];
-    float M = -3.0e38f;
-    for (int u = u0; u < u1; ++u) M = fmaxf(M, part[(size_t)plist[u] * ustride + col]);
-    float Lsum = 0.0f;
+    float M = -3.0e38f, Lsum = 0.0f;
     float acc[kMaxClasses];
 #pragma unroll
     for (int k = 0; k < kMaxClasses; ++k) acc[k] = 0.0f;
-    for (int u = u0; u < u1; ++u) {
-        const float* pu = part + (size_t)plist[u] * ustride + col;
-        const float sc = __builtin_amdgcn_exp2f((pu[0] - M) * c);
-        Lsum += pu[kBT] * sc;
+    for (int u = u0 + g; u < u1; u += 4) {
+        const float* pu = part + (size_t)plist[u] * ustride + tcol;
+        const float m = pu[0];
+        const float Mn = fmaxf(M, m);
+        const float so = __builtin_amdgcn_exp2f((M - Mn) * c), sn = __builtin_amdgcn_exp2f((m - Mn) * c);
+        Lsum = Lsum * so + pu[kBT] * sn;
 #pragma unroll
         for (int k = 0; k < kMaxClasses; ++k)
-            if (k < d) acc[k] += pu[(size_t)(2 + k) * kBT] * sc;
+            if (k < d) acc[k] = acc[k] * so + pu[(size_t)(2 + k) * kBT] * sn;
+        M = Mn;
     }
-    const float inv = 1.0f / Lsum;
-    int best = 0;
-    float bv = acc[0] * inv;
+    red[g][0][col] = M;
+    red[g][1][col] = Lsum;
 #pragma unroll
-    for (int k = 0; k < kMaxClasses; ++k) {
-        if (k < d) {
-            const float v = acc[k] * inv;
-            pred[(size_t)k * HW + t] = v;
+    for (int k = 0; k < kMaxClasses; ++k)
+        if (k < d) red[g][2 + k][col] = acc[k];
+    __syncthreads();
+    if (g == 0) {
+        float Mt = fmaxf(fmaxf(red[0][0][col], red[1][0][col]), fmaxf(red[2][0][col], red[3][0][col]));
+        float sc[4], Lt = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = __builtin_amdgcn_exp2f((red[q][0][col] - Mt) * c);
+            Lt += red[q][1][col] * sc[q];
+        }
+        const float inv = 1.0f / Lt;
+        int best = 0;
+        float bv = -1.0f;
+        for (int k = 0; k < d; ++k) {
+            const float v = (red[0][2 + k][col] * sc[0] + red[1][2 + k][col] * sc[1] + red[2][2 + k][col] * sc[2] +
+                             red[3][2 + k][col] * sc[3]) * inv;
+            outv[k][col] = v;
+            if (t < HW) pred[(size_t)k * HW + t] = v;
             if (v > bv) { bv = v; best = k; }
         }
+        clsv[col] = (uint8_t)best;
+        if (t < HW) cls[t] = (uint8_t)best;
     }
-    cls[t] = (uint8_t)best;
+    if (!lab_hi) return;
+    __syncthreads();
+    // pack this block's two label tiles: chunk = (tile, s, lane) -> 8 bf16
+    {
+        const int tl = tid >> 7, s = (tid >> 6) & 1, lane = tid & 63, k = lane & 31;
+        const int tile = blockIdx.x * 2 + tl;
+        bf16x8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pc = tl * 32 + lab_row(s, lane, e);           // column within the block
+            const bool ok = blockIdx.x * 64 + pc < HW && k < d;
+            float v = 0.0f;
+            if (ok) v = prob ? outv[k][pc] : (clsv[pc] == k ? 1.0f : 0.0f);
+            const float hi = bf16_round(v);
+            oh[e] = (bf16_t)hi;
+            ol[e] = (bf16_t)(v - hi);
+        }
+        const size_t off = ((size_t)tile * 128 + (size_t)s * 64 + lane) * 8;
+        *(bf16x8*)(lab_hi + off) = oh;
+        if (lab_lo && prob) *(bf16x8*)(lab_lo + off) = ol;
+    }
 }
 
 // Nearest up-sampling of the class map (reference inference_utils.py:74-75; argmax and nearest

@@ -186,7 +186,7 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
 
 template <typename T>
 void launch_push(const void* src, bf16_t* dst, int HW, hipStream_t s) {
-    hipLaunchKernelGGL(push_kernel<T>, dim3((HW + 63) / 64), dim3(256), 0, s, (const T*)src, dst, HW);
+    hipLaunchKernelGGL(push_kernel<T>, dim3((HW + 63) / 64, kC / 64), dim3(256), 0, s, (const T*)src, dst, HW);
 }
 
 int push_features(vosprop_ctx* ctx, const void* src, int dtype, bf16_t* dst, hipStream_t s) {
@@ -214,7 +214,7 @@ void launch_prop(const LastProp& lp, hipStream_t s) {
 // One propagation: sampled frames `idx` (history indices, ring slot = idx % cap) against the target slot.
 int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int frame_idx, int target_slot, int d,
               bool prob, bool lab_lo, float sigma1, float sigma2, float temperature, float* pred, uint8_t* cls,
-              hipStream_t s) {
+              bf16_t* new_lab_hi, bf16_t* new_lab_lo, hipStream_t s) {
     if (n_ref < 1 || n_ref > kMaxRef) return fail(ctx, VOSPROP_E_INVALID, "n_ref out of range");
     if (d < 1 || d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "d > VOSPROP_MAX_CLASSES");
     if (!(temperature > 0.0f)) return fail(ctx, VOSPROP_E_UNSUPPORTED, "temperature must be > 0");
@@ -255,8 +255,8 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.part = ctx->part;
     launch_prop(lp, s);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(combine_kernel, dim3(ctx->TT), dim3(kBT), 0, s, ctx->part, plan->d_off, plan->d_list, d, ctx->HW,
-                       a.c, pred, cls);
+    hipLaunchKernelGGL(combine_kernel, dim3(ctx->HWp / 64 + (ctx->HWp % 64 ? 1 : 0)), dim3(256), 0, s, ctx->part, plan->d_off,
+                       plan->d_list, d, ctx->HW, a.c, pred, cls, new_lab_hi, new_lab_lo, prob ? 1 : 0);
     HIP_TRY(ctx, hipGetLastError());
 #ifdef VOSPROP_STAMP
     lp.args.dbg = nullptr;   // set by vosprop_debug_stamps
@@ -453,12 +453,9 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     for (int n = 0; n < n_ref; ++n) slots[n] = idx[n] % R.cap;
     const bool prob = ctx->cfg.probability != 0;
     uint8_t* cls_slot = R.cls + (size_t)slot * ctx->HWp;
+    // combine_kernel also writes the new label of this frame (reference inference_utils.py:67-71) into its ring slot
     rc = propagate(ctx, R, slots, n_ref, f, slot, ctx->d, prob, prob, ctx->cfg.sigma1, ctx->cfg.sigma2,
-                   ctx->cfg.temperature, ctx->pred_buf, cls_slot, s);
-    if (rc) return rc;
-    // new label of this frame (reference inference_utils.py:67-71)
-    if (prob) rc = pack_labels_from_f32(ctx, ctx->pred_buf, (size_t)ctx->HW, ctx->d, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s);
-    else rc = pack_labels_from_cls(ctx, cls_slot, R.lab_hi + slot * lab_slot, s);
+                   ctx->cfg.temperature, ctx->pred_buf, cls_slot, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s);
     if (rc) return rc;
     if (pred_out_dev)
         HIP_TRY(ctx, hipMemcpyAsync(pred_out_dev, ctx->pred_buf, (size_t)ctx->d * ctx->HW * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -506,7 +503,7 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
     int rc = push_features(ctx, target_dev, feat_dtype, R.feat + (size_t)n_ref * ctx->HWp * kC, s);
     if (rc) return rc;
     return propagate(ctx, R, slots, n_ref, frame_idx, n_ref, d, probability != 0, true, sigma1, sigma2, temperature,
-                     out_dev, ctx->cls_tmp, s);
+                     out_dev, ctx->cls_tmp, nullptr, nullptr, s);
 }
 
 int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out) {
