@@ -66,7 +66,8 @@ typedef struct vosprop_config {
     float sigma2;         /* --sigma_2      (src/inference.py:30), default 21                    */
     float temperature;    /* --temperature  (src/inference.py:26), default 1; must be > 0        */
     int probability;      /* --probability  (src/inference.py:42): 0 = propagate one-hot labels  */
-    int topk;             /* 0 = dense (the reference); k>0 = keep the k largest A[.,t] per target pixel */
+    int topk;             /* 0 = dense (the reference); 1..32 = keep the k largest A[.,t] per target pixel, zero the rest,
+                             no renormalisation (NOT in the reference; label-propagation mode only; two kernel passes) */
     int precision;        /* VOSPROP_PREC_*                                                      */
     int ring_capacity;    /* 0 = auto: max(frame_range + 4, ref_num) + 1 frames                  */
     int reserved[8];      /* zero                                                                */

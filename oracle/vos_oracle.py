@@ -79,7 +79,7 @@ def feature_map_size(H, W):
 
 
 def predict(ref, target, ref_label, weight_dense, weight_sparse, frame_idx, take_range, ref_num,
-            temperature, probability_propagation):
+            temperature, probability_propagation, topk=0):
     """src/model/predict.py:19-71, op for op.
 
     ref (T,C,H,W) f32; target (C,H,W); ref_label (d,T,HW); weights (HW,HW) or None.
@@ -108,6 +108,11 @@ def predict(ref, target, ref_label, weight_dense, weight_sparse, frame_idx, take
         else:
             S = S.mul(weight_dense)
     S = S.view(-1, H * W)
+    if topk and topk < S.shape[0]:
+        # NOT in the reference (parity unpinned by the reference, pinned by k >= N*HW == dense):
+        # per target pixel keep the k largest entries of the weighted affinity, zero the rest, no renormalisation.
+        kth = S.topk(topk, dim=0).values[-1:]
+        S = torch.where(S >= kth, S, torch.zeros_like(S))
     return lab_sel.float().mm(S.float())
 
 
@@ -131,7 +136,7 @@ class VideoState:
         self.frame_idx = 0
 
 
-def rollout_step(state, features, frame_range, ref_num, temperature):
+def rollout_step(state, features, frame_range, ref_num, temperature, topk=0):
     """One iteration of the loop body, src/utils/inference_utils.py:33-75.
 
     features (1,C,H_d,W_d) f32.  Frame 0 only seeds the history.  Returns (prediction (d,HW) f32,
@@ -143,7 +148,7 @@ def rollout_step(state, features, frame_range, ref_num, temperature):
         state.frame_idx = 1
         return None, None
     pred = predict(state.feats_history, features[0], state.label_history, state.w_dense, state.w_sparse,
-                   state.frame_idx, frame_range, ref_num, temperature, state.prob)
+                   state.frame_idx, frame_range, ref_num, temperature, state.prob, topk)
     if state.prob:
         new_label = pred.unsqueeze(1)                                # :68
     else:
@@ -158,13 +163,13 @@ def rollout_step(state, features, frame_range, ref_num, temperature):
 
 
 def rollout(first_label, feats, frame_range=40, ref_num=9, temperature=1.0, sigma1=8.0, sigma2=21.0,
-            probability_propagation=False):
+            probability_propagation=False, topk=0):
     """`inference_single` for one video with the encoder outputs supplied (T,C,H_d,W_d).
     Returns (preds (T-1,d,HW) f32, masks (T-1,H,W) u8)."""
     st = VideoState(first_label, sigma1, sigma2, probability_propagation)
     preds, masks = [], []
     for t in range(feats.shape[0]):
-        p, m = rollout_step(st, torch.as_tensor(feats[t:t + 1]), frame_range, ref_num, temperature)
+        p, m = rollout_step(st, torch.as_tensor(feats[t:t + 1]), frame_range, ref_num, temperature, topk)
         if p is not None:
             preds.append(p.numpy())
             masks.append(m.numpy().astype(np.uint8))

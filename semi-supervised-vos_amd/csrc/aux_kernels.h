@@ -65,9 +65,18 @@ __global__ void pack_cls_kernel(const uint8_t* __restrict__ cls, bf16_t* __restr
 
 // General f32 labels L[k][p] (row stride ld floats between classes) -> hi (+ lo) bf16 parts.
 __global__ void pack_f32_kernel(const float* __restrict__ L, size_t ld, int d, bf16_t* __restrict__ lab_hi,
-                                bf16_t* __restrict__ lab_lo, int HW, int tiles) {
+                                bf16_t* __restrict__ lab_lo, uint8_t* __restrict__ cls, int HW, int tiles) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= tiles * 128) return;
+    if (cls && gid < HW) {   // class index of pixel gid = arg-max of its label column (exact for one-hot labels)
+        int best = 0;
+        float bv = L[gid];
+        for (int k = 1; k < d; ++k) {
+            const float v = L[(size_t)k * ld + gid];
+            if (v > bv) { bv = v; best = k; }
+        }
+        cls[gid] = (uint8_t)best;
+    }
     const int tile = gid >> 7, s = (gid >> 6) & 1, lane = gid & 63;
     const int k = lane & 31;
     bf16x8 oh, ol;
@@ -83,6 +92,9 @@ __global__ void pack_f32_kernel(const float* __restrict__ L, size_t ld, int d, b
     *(bf16x8*)(lab_hi + (size_t)gid * 8) = oh;
     if (lab_lo) *(bf16x8*)(lab_lo + (size_t)gid * 8) = ol;
 }
+
+__device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t* clsv, int d, int HW, int prob,
+                                         bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo);
 
 // Merge the partials of target pixels, normalise, arg-max, and write the new frame's labels in MFMA operand order.
 //   out[k,t] = sum_u Y_u[k] 2^((m_u - M) c) / sum_u l_u 2^((m_u - M) c)      (reference predict.py:55-70)
@@ -148,25 +160,146 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
     }
     if (!lab_hi) return;
     __syncthreads();
-    // pack this block's two label tiles: chunk = (tile, s, lane) -> 8 bf16
-    {
-        const int tl = tid >> 7, s = (tid >> 6) & 1, lane = tid & 63, k = lane & 31;
-        const int tile = blockIdx.x * 2 + tl;
-        bf16x8 oh, ol;
+    pack_block_labels(outv, clsv, d, HW, prob, lab_hi, lab_lo);
+}
+
+// Label tiles of one 64-pixel block in MFMA A-operand order, from LDS copies of the block's results (256 threads).
+__device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t* clsv, int d, int HW, int prob,
+                                         bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo) {
+    const int tid = threadIdx.x;
+    const int tl = tid >> 7, s = (tid >> 6) & 1, lane = tid & 63, k = lane & 31;
+    const int tile = blockIdx.x * 2 + tl;
+    bf16x8 oh, ol;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int pc = tl * 32 + lab_row(s, lane, e);           // column within the block
-            const bool ok = blockIdx.x * 64 + pc < HW && k < d;
-            float v = 0.0f;
-            if (ok) v = prob ? outv[k][pc] : (clsv[pc] == k ? 1.0f : 0.0f);
-            const float hi = bf16_round(v);
-            oh[e] = (bf16_t)hi;
-            ol[e] = (bf16_t)(v - hi);
-        }
-        const size_t off = ((size_t)tile * 128 + (size_t)s * 64 + lane) * 8;
-        *(bf16x8*)(lab_hi + off) = oh;
-        if (lab_lo && prob) *(bf16x8*)(lab_lo + off) = ol;
+    for (int e = 0; e < 8; ++e) {
+        const int pc = tl * 32 + lab_row(s, lane, e);           // column within the block
+        const bool ok = blockIdx.x * 64 + pc < HW && k < d;
+        float v = 0.0f;
+        if (ok) v = prob ? outv[k][pc] : (clsv[pc] == k ? 1.0f : 0.0f);
+        const float hi = bf16_round(v);
+        oh[e] = (bf16_t)hi;
+        ol[e] = (bf16_t)(v - hi);
     }
+    const size_t off = ((size_t)tile * 128 + (size_t)s * 64 + lane) * 8;
+    *(bf16x8*)(lab_hi + off) = oh;
+    if (lab_lo && prob) *(bf16x8*)(lab_lo + off) = ol;
+}
+
+// Top-k, between the passes: per target pixel merge the sorted group-maximum lists of all partial slots (2 half-wave
+// lists per slot) and take the k-th largest value = lower bound of the k-th largest weighted exponent; also the exact
+// column max of the raw scores; zero the candidate counter.  grid = ceil(HWp/256), block = 256 (one thread per pixel).
+__global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ part, const int* __restrict__ plist_off,
+                                                          const int* __restrict__ plist, int k, int HW, int HWp,
+                                                          float* __restrict__ thr, float* __restrict__ mfin,
+                                                          unsigned* __restrict__ cnt) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= HWp) return;
+    cnt[t] = 0;
+    if (t >= HW) { thr[t] = 3.0e38f; mfin[t] = 0.0f; return; }
+    const int tt = t / kBT, tcol = t % kBT;
+    const size_t ustride = (size_t)(1 + 2 * kTopkMax) * kBT;
+    float lst[kTopkMax];
+#pragma unroll
+    for (int i = 0; i < kTopkMax; ++i) lst[i] = -3.0e38f;
+    float M = -3.0e38f;
+    for (int u = plist_off[tt]; u < plist_off[tt + 1]; ++u) {
+        const float* pu = part + (size_t)plist[u] * ustride + tcol;
+        M = fmaxf(M, pu[0]);
+        for (int hh = 0; hh < 2; ++hh) {
+            for (int i = 0; i < kTopkMax; ++i) {
+                float x = pu[(size_t)(1 + hh * kTopkMax + i) * kBT];
+                if (x <= lst[kTopkMax - 1]) break;   // both lists are descending
+#pragma unroll
+                for (int q = 0; q < kTopkMax; ++q) {
+                    const float hi = fmaxf(lst[q], x);
+                    x = fminf(lst[q], x);
+                    lst[q] = hi;
+                }
+            }
+        }
+    }
+    float v = lst[0];
+#pragma unroll
+    for (int q = 1; q < kTopkMax; ++q)
+        if (q < k) v = lst[q];
+    thr[t] = v;
+    mfin[t] = M;
+}
+
+struct TopkCombineArgs {
+    const float* part;       // pass-2 partials: rows (m, l)
+    const int* plist_off;
+    const int* plist;
+    const float* thr;
+    const float* mfin;
+    const unsigned* cnt;
+    const uint2* cand;
+    const uint8_t* cls_ring; // [cap][HWp] class index of every reference pixel
+    int slot[kMaxRef];
+    int k, d, HW, HWp;
+    float c;
+};
+
+// Top-k, after pass 2: denominators from the partials, the k largest candidates of each target pixel summed per class.
+// grid = ceil(HW/64), block = 256 (threads 0-63: one target pixel each; all 256 then pack the block's label tiles).
+__global__ __launch_bounds__(256) void topk_combine_kernel(const TopkCombineArgs a, float* __restrict__ pred,
+                                                           uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi,
+                                                           bf16_t* __restrict__ lab_lo) {
+    __shared__ float outv[kMaxClasses][64];
+    __shared__ uint8_t clsv[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int col = tid, t = blockIdx.x * 64 + col;
+        for (int k = 0; k < a.d; ++k) outv[k][col] = 0.0f;
+        clsv[col] = 0;
+        if (t < a.HW) {
+            const int tt = t / kBT, tcol = t % kBT;
+            float L = 0.0f;
+            for (int u = a.plist_off[tt]; u < a.plist_off[tt + 1]; ++u) L += a.part[((size_t)a.plist[u] * 2 + 1) * kBT + tcol];
+            unsigned n = a.cnt[t];
+            if (n > (unsigned)kTopkCap) n = kTopkCap;
+            const uint2* cd = a.cand + (size_t)t * kTopkCap;
+            // k-th largest candidate exponent (candidates are few: a register list with early-out insertion)
+            float lst[kTopkMax];
+#pragma unroll
+            for (int i = 0; i < kTopkMax; ++i) lst[i] = -3.0e38f;
+            for (unsigned i = 0; i < n; ++i) {
+                float x = __uint_as_float(cd[i].x);
+                if (x <= lst[kTopkMax - 1]) continue;
+#pragma unroll
+                for (int q = 0; q < kTopkMax; ++q) {
+                    const float hi = fmaxf(lst[q], x);
+                    x = fminf(lst[q], x);
+                    lst[q] = hi;
+                }
+            }
+            float tau = lst[0];
+#pragma unroll
+            for (int q = 1; q < kTopkMax; ++q)
+                if (q < a.k) tau = lst[q];
+            const float mc = a.mfin[t] * a.c, inv = 1.0f / L;
+            for (unsigned i = 0; i < n; ++i) {
+                const float E = __uint_as_float(cd[i].x);
+                if (E < tau) continue;
+                const unsigned row = cd[i].y;
+                const unsigned fn = row / (unsigned)a.HWp, px = row - fn * (unsigned)a.HWp;
+                const int kcls = a.cls_ring[(size_t)a.slot[fn] * a.HWp + px];
+                if (kcls < a.d) outv[kcls][col] += __builtin_amdgcn_exp2f(E - mc) * inv;
+            }
+            int best = 0;
+            float bv = -1.0f;
+            for (int k = 0; k < a.d; ++k) {
+                const float v = outv[k][col];
+                pred[(size_t)k * a.HW + t] = v;
+                if (v > bv) { bv = v; best = k; }
+            }
+            clsv[col] = (uint8_t)best;
+            cls[t] = (uint8_t)best;
+        }
+    }
+    if (!lab_hi) return;
+    __syncthreads();
+    pack_block_labels(outv, clsv, a.d, a.HW, 0, lab_hi, lab_lo);
 }
 
 // Nearest up-sampling of the class map (reference inference_utils.py:74-75; argmax and nearest

@@ -14,6 +14,8 @@ constexpr int kMaxClasses = 32;
 constexpr int kMaxRef = 64;
 constexpr int kCoordCh = 16;       // extra K channels that carry the spatial prior
 constexpr int kContinuousFrame = 4;   // reference src/config.py:13
+constexpr int kTopkMax = 32;       // largest k of the top-k variant (list length kept per lane in pass 1)
+constexpr int kTopkCap = 16 * kTopkMax;   // candidates per target pixel that can exceed the pass-1 bound (see prop_bf16.h)
 constexpr int kXcd = 8;            // XCDs: blocks b and b+8 share an L2 (placement is a speed matter only)
 
 typedef __bf16 bf16_t;
@@ -86,6 +88,12 @@ struct PropArgs {
     float c;                    // temperature * log2(e)
     double g1, g2;              // 1 / (sigma^2 * temperature) for sigma1, sigma2
     double two_over_w, gamma;   // 2/W_d, 1 + 1/W_d^2
+    int part_rows;              // rows of one partial slot: 2 + d (dense), 1 + 2*kTopkMax (top-k pass 1), 2 (top-k pass 2)
+    // top-k variant (two passes, see prop_bf16.h)
+    const float* tk_thr;        // [HWp] pass 2: lower bound of the k-th largest weighted exponent of each target pixel
+    const float* tk_m;          // [HWp] pass 2: column max of the raw scores (exact softmax max, from pass 1)
+    unsigned* tk_cnt;           // [HWp] pass 2: number of candidates appended per target pixel
+    uint2* tk_cand;             // [HWp][kTopkCap] pass 2: (exponent bits, reference row id = n*HWp + p)
     unsigned long long* dbg;    // diagnostic builds only (-DVOSPROP_STAMP): per-wave cycle sums; else nullptr
 };
 

@@ -29,9 +29,13 @@ struct Ring {
 
 struct LastProp {
     bool valid = false;
-    PropArgs args;
+    PropArgs args;        // dense: the launch; top-k: pass 2 (pass 1 differs in part_rows only)
     int grid = 0;
     bool prob = false, lab_lo = false;
+    int topk = 0;
+    int rows_pass1 = 0;
+    const int* d_off = nullptr;    // plan lists (top-k select between the passes)
+    const int* d_list = nullptr;
 };
 
 // Device copy of the partial-slot lists of one work decomposition (depends only on TT, NT).
@@ -55,6 +59,10 @@ struct vosprop_ctx {
     size_t part_bytes = 0;
     float* pred_buf = nullptr;     // (kMaxClasses, HW) f32
     uint8_t* cls_tmp = nullptr;    // (HWp)
+    float* tk_thr = nullptr;       // top-k scratch (allocated when cfg.topk > 0)
+    float* tk_m = nullptr;
+    unsigned* tk_cnt = nullptr;
+    uint2* tk_cand = nullptr;
     // video state
     bool in_video = false;
     int frame_idx = 0;
@@ -200,26 +208,40 @@ int push_features(vosprop_ctx* ctx, const void* src, int dtype, bf16_t* dst, hip
     return VOSPROP_OK;
 }
 
-void launch_prop(const LastProp& lp, hipStream_t s) {
+void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream_t s) {
     const dim3 grid(lp.grid), block(kWaves * 64);
+    if (mode == 1) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 1>), grid, block, 0, s, a); return; }
+    if (mode == 2) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 2>), grid, block, 0, s, a); return; }
     if (lp.prob) {
-        if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<true, true>), grid, block, 0, s, lp.args);
-        else hipLaunchKernelGGL((prop_bf16_kernel<true, false>), grid, block, 0, s, lp.args);
+        if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<true, true, 0>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((prop_bf16_kernel<true, false, 0>), grid, block, 0, s, a);
     } else {
-        if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<false, true>), grid, block, 0, s, lp.args);
-        else hipLaunchKernelGGL((prop_bf16_kernel<false, false>), grid, block, 0, s, lp.args);
+        if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<false, true, 0>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((prop_bf16_kernel<false, false, 0>), grid, block, 0, s, a);
     }
+}
+
+// The propagation kernel(s) of one step: dense = one launch; top-k = pass 1, select, pass 2.
+void launch_prop(const vosprop_ctx* ctx, const LastProp& lp, hipStream_t s) {
+    if (lp.topk == 0) { launch_prop_mode(lp, lp.args, 0, s); return; }
+    PropArgs a1 = lp.args;
+    a1.part_rows = lp.rows_pass1;
+    launch_prop_mode(lp, a1, 1, s);
+    hipLaunchKernelGGL(topk_select_kernel, dim3((ctx->HWp + 255) / 256), dim3(256), 0, s, lp.args.part, lp.d_off, lp.d_list,
+                       lp.topk, ctx->HW, ctx->HWp, ctx->tk_thr, ctx->tk_m, ctx->tk_cnt);
+    launch_prop_mode(lp, lp.args, 2, s);
 }
 
 // One propagation: sampled frames `idx` (history indices, ring slot = idx % cap) against the target slot.
 int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int frame_idx, int target_slot, int d,
               bool prob, bool lab_lo, float sigma1, float sigma2, float temperature, float* pred, uint8_t* cls,
               bf16_t* new_lab_hi, bf16_t* new_lab_lo, hipStream_t s) {
+    const int topk = ctx->cfg.topk;
     if (n_ref < 1 || n_ref > kMaxRef) return fail(ctx, VOSPROP_E_INVALID, "n_ref out of range");
     if (d < 1 || d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "d > VOSPROP_MAX_CLASSES");
     if (!(temperature > 0.0f)) return fail(ctx, VOSPROP_E_UNSUPPORTED, "temperature must be > 0");
     if (ctx->cfg.precision != VOSPROP_PREC_BF16) return fail(ctx, VOSPROP_E_UNSUPPORTED, "precision not built");
-    if (ctx->cfg.topk != 0) return fail(ctx, VOSPROP_E_UNSUPPORTED, "top-k not built yet");
+    if (topk != 0 && prob) return fail(ctx, VOSPROP_E_UNSUPPORTED, "top-k is built for label propagation only");
     LastProp lp;
     PropArgs& a = lp.args;
     memset(&a, 0, sizeof(a));
@@ -249,14 +271,36 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.gamma = 1.0 + 1.0 / ((double)ctx->cfg.feat_w * ctx->cfg.feat_w);
     lp.grid = kXcd * plan->map.wg_per_xcd;
     lp.prob = prob;
-    lp.lab_lo = lab_lo;
-    rc = ensure_part(ctx, (size_t)plan->n_parts * (2 + d) * kBT * sizeof(float));
+    lp.lab_lo = topk ? false : lab_lo;
+    lp.topk = topk;
+    lp.rows_pass1 = 1 + 2 * kTopkMax;
+    lp.d_off = plan->d_off;
+    lp.d_list = plan->d_list;
+    const int rows_alloc = topk ? lp.rows_pass1 : 2 + d;
+    rc = ensure_part(ctx, (size_t)plan->n_parts * rows_alloc * kBT * sizeof(float));
     if (rc) return rc;
     a.part = ctx->part;
-    launch_prop(lp, s);
+    a.part_rows = topk ? 2 : 2 + d;
+    a.tk_thr = ctx->tk_thr;
+    a.tk_m = ctx->tk_m;
+    a.tk_cnt = ctx->tk_cnt;
+    a.tk_cand = ctx->tk_cand;
+    launch_prop(ctx, lp, s);
     HIP_TRY(ctx, hipGetLastError());
-    hipLaunchKernelGGL(combine_kernel, dim3(ctx->HWp / 64 + (ctx->HWp % 64 ? 1 : 0)), dim3(256), 0, s, ctx->part, plan->d_off,
-                       plan->d_list, d, ctx->HW, a.c, pred, cls, new_lab_hi, new_lab_lo, prob ? 1 : 0);
+    const dim3 cgrid(ctx->HWp / 64 + (ctx->HWp % 64 ? 1 : 0));
+    if (topk) {
+        TopkCombineArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.part = ctx->part; ca.plist_off = plan->d_off; ca.plist = plan->d_list;
+        ca.thr = ctx->tk_thr; ca.mfin = ctx->tk_m; ca.cnt = ctx->tk_cnt; ca.cand = ctx->tk_cand;
+        ca.cls_ring = ring.cls;
+        for (int n = 0; n < n_ref; ++n) ca.slot[n] = slots[n];
+        ca.k = topk; ca.d = d; ca.HW = ctx->HW; ca.HWp = ctx->HWp; ca.c = a.c;
+        hipLaunchKernelGGL(topk_combine_kernel, cgrid, dim3(256), 0, s, ca, pred, cls, new_lab_hi, new_lab_lo);
+    } else {
+        hipLaunchKernelGGL(combine_kernel, cgrid, dim3(256), 0, s, ctx->part, plan->d_off, plan->d_list, d, ctx->HW, a.c, pred,
+                           cls, new_lab_hi, new_lab_lo, prob ? 1 : 0);
+    }
     HIP_TRY(ctx, hipGetLastError());
 #ifdef VOSPROP_STAMP
     lp.args.dbg = nullptr;   // set by vosprop_debug_stamps
@@ -269,7 +313,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     st.hw = ctx->HW;
     st.workgroups = lp.grid;
     st.tiles_per_wg = (int)(((long long)ctx->TT * n_ref * ctx->tiles + lp.grid - 1) / lp.grid);
-    st.flops = 2.0 * n_ref * HW * HW * kC + 2.0 * d * n_ref * HW * HW;
+    st.flops = (topk ? 2.0 : 1.0) * 2.0 * n_ref * HW * HW * kC + (topk ? 0.0 : 2.0 * d * n_ref * HW * HW);   // top-k: 2 passes
     st.bytes = n_ref * HW * kC * 2.0 + HW * kC * 2.0 + n_ref * HW + d * HW * 4.0;
     return VOSPROP_OK;
 }
@@ -282,9 +326,9 @@ int pack_labels_from_cls(vosprop_ctx* ctx, const uint8_t* cls, bf16_t* lab_hi, h
 }
 
 int pack_labels_from_f32(vosprop_ctx* ctx, const float* L, size_t ld, int d, bf16_t* lab_hi, bf16_t* lab_lo,
-                         hipStream_t s) {
+                         uint8_t* cls, hipStream_t s) {
     const int n = ctx->tiles * 128;
-    hipLaunchKernelGGL(pack_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, L, ld, d, lab_hi, lab_lo, ctx->HW,
+    hipLaunchKernelGGL(pack_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, L, ld, d, lab_hi, lab_lo, cls, ctx->HW,
                        ctx->tiles);
     HIP_TRY(ctx, hipGetLastError());
     return VOSPROP_OK;
@@ -356,7 +400,8 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
     if (cfg->ref_num < 1 || cfg->ref_num > kMaxRef || cfg->frame_range < 0) return VOSPROP_E_INVALID;
     if (!(cfg->temperature > 0.0f) || !(cfg->sigma1 > 0.0f) || !(cfg->sigma2 > 0.0f)) return VOSPROP_E_INVALID;
     if (cfg->precision != VOSPROP_PREC_BF16) return VOSPROP_E_UNSUPPORTED;
-    if (cfg->topk != 0) return VOSPROP_E_UNSUPPORTED;
+    if (cfg->topk < 0 || cfg->topk > kTopkMax) return VOSPROP_E_UNSUPPORTED;
+    if (cfg->topk != 0 && cfg->probability) return VOSPROP_E_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return VOSPROP_E_HIP;
     if (hipSetDevice(cfg->device) != hipSuccess) return VOSPROP_E_HIP;
@@ -376,6 +421,13 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
     if (!rc) rc = build_coord_table(ctx);
     if (!rc && hipMalloc((void**)&ctx->pred_buf, (size_t)kMaxClasses * ctx->HW * sizeof(float)) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipMalloc((void**)&ctx->cls_tmp, (size_t)ctx->HWp) != hipSuccess) rc = VOSPROP_E_HIP;
+    if (!rc && cfg->topk > 0) {
+        if (hipMalloc((void**)&ctx->tk_thr, (size_t)ctx->HWp * 4) != hipSuccess ||
+            hipMalloc((void**)&ctx->tk_m, (size_t)ctx->HWp * 4) != hipSuccess ||
+            hipMalloc((void**)&ctx->tk_cnt, (size_t)ctx->HWp * 4) != hipSuccess ||
+            hipMalloc((void**)&ctx->tk_cand, (size_t)ctx->HWp * kTopkCap * sizeof(uint2)) != hipSuccess)
+            rc = VOSPROP_E_HIP;
+    }
     if (rc) { vosprop_destroy(ctx); return rc; }
     *out = ctx;
     return VOSPROP_OK;
@@ -395,6 +447,10 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     }
     if (ctx->pred_buf) (void)hipFree(ctx->pred_buf);
     if (ctx->cls_tmp) (void)hipFree(ctx->cls_tmp);
+    if (ctx->tk_thr) (void)hipFree(ctx->tk_thr);
+    if (ctx->tk_m) (void)hipFree(ctx->tk_m);
+    if (ctx->tk_cnt) (void)hipFree(ctx->tk_cnt);
+    if (ctx->tk_cand) (void)hipFree(ctx->tk_cand);
     delete ctx;
 }
 
@@ -497,7 +553,7 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
         if (rc) return rc;
         // ref_label (d, T, HW): class stride T*HW floats, frame idx[n]
         rc = pack_labels_from_f32(ctx, ref_label_dev + (size_t)idx[n] * ctx->HW, (size_t)T * ctx->HW, d,
-                                  R.lab_hi + n * lab_slot, R.lab_lo + n * lab_slot, s);
+                                  R.lab_hi + n * lab_slot, R.lab_lo + n * lab_slot, R.cls + (size_t)n * ctx->HWp, s);
         if (rc) return rc;
     }
     int rc = push_features(ctx, target_dev, feat_dtype, R.feat + (size_t)n_ref * ctx->HWp * kC, s);
@@ -520,9 +576,9 @@ int vosprop_time_last_propagation(vosprop_ctx* ctx, int iters, void* stream, dou
     hipEvent_t e0, e1;
     HIP_TRY(ctx, hipEventCreate(&e0));
     HIP_TRY(ctx, hipEventCreate(&e1));
-    launch_prop(ctx->last, s);   // warm
+    launch_prop(ctx, ctx->last, s);   // warm
     HIP_TRY(ctx, hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) launch_prop(ctx->last, s);
+    for (int i = 0; i < iters; ++i) launch_prop(ctx, ctx->last, s);
     HIP_TRY(ctx, hipEventRecord(e1, s));
     HIP_TRY(ctx, hipEventSynchronize(e1));
     float ms = 0.0f;
@@ -546,7 +602,7 @@ int vosprop_debug_stamps(vosprop_ctx* ctx, unsigned long long* out_host, int max
     HIP_TRY(ctx, hipMemset(d, 0, n * 8));
     LastProp lp = ctx->last;
     lp.args.dbg = d;
-    launch_prop(lp, nullptr);
+    launch_prop(ctx, lp, nullptr);
     HIP_TRY(ctx, hipDeviceSynchronize());
     HIP_TRY(ctx, hipMemcpy(out_host, d, n * 8, hipMemcpyDeviceToHost));
     (void)hipFree(d);

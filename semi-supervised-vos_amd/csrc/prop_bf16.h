@@ -251,7 +251,106 @@ __device__ __forceinline__ void tile_softmax(const LabFrag<LAB_LO>& lab, int h, 
     }
 }
 
-template <bool PROB, bool LAB_LO>
+// ---------------------------------------------------------------------------------------------------------------
+// Top-k variant (NOT in the reference): per target pixel keep the k largest entries of the
+// weighted affinity A[.,t] = P[.,t] w[.,t], zero the rest, no renormalisation (k >= N*HW reproduces the dense result).
+// Ranking by A is ranking by the exponent E = S_w c - gQ_t c (the softmax max and denominator are column constants), so:
+//   pass 1 (MODE 1): no exponentials.  Every lane keeps, sorted in registers, the kTopkMax largest GROUP maxima it has seen
+//           (a group = the 16 rows of one tile a lane owns) and the column max of the raw scores.  The k-th largest group
+//           maximum G_k of a column is a lower bound of its k-th largest element, and at most 16k elements reach it.
+//   pass 2 (MODE 2): exact softmax denominators against the now known column max (no rescale path), and every element
+//           with E >= G_k is appended to a per-pixel candidate list (rare: ~k..2k per pixel); topk_combine_kernel picks
+//           the k largest candidates and sums them per class.
+struct TopkList {
+    float v[kTopkMax];   // descending
+};
+
+__device__ __forceinline__ float vmaxf(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vminf(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max16v(const float (&v)[16]) {
+    float t0, t1, t2, t3, t4, r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(v[3]), "v"(v[4]), "v"(v[5]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t2) : "v"(v[6]), "v"(v[7]), "v"(v[8]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(v[9]), "v"(v[10]), "v"(v[11]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t4) : "v"(v[12]), "v"(v[13]), "v"(v[14]));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(t0), "v"(t1), "v"(t2));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(t3), "v"(t4), "v"(v[15]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(t0), "v"(t3));
+    return r;
+}
+
+__device__ __forceinline__ void mask_tail_rows(f32x16& S, f32x16& Sw, int h, int rows_valid) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        if (acc_row(r, h) >= rows_valid) {
+            S[r] = kNegBig;
+            Sw[r] = kNegBig;
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_topk_pass1(f32x16& S, f32x16& Sw, float& colmax, TopkList& lst, int h, float c,
+                                                float kq, bool tail, int rows_valid) {
+    if (tail) {
+        asm volatile("; tail tile" ::: "memory");
+        mask_tail_rows(S, Sw, h, rows_valid);
+    }
+    float E[16], Sr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        E[r] = __builtin_fmaf(Sw[r], c, -kq);
+        Sr[r] = S[r];
+    }
+    colmax = vmaxf(colmax, max16v(Sr));
+    float x = max16v(E);
+#pragma unroll
+    for (int i = 0; i < kTopkMax; ++i) {   // insert x into the descending list (2 ops per slot, branch-free)
+        const float hi = vmaxf(lst.v[i], x);
+        x = vminf(lst.v[i], x);
+        lst.v[i] = hi;
+    }
+}
+
+__device__ __forceinline__ void tile_topk_pass2(f32x16& S, f32x16& Sw, float mc, float& lsum, int h, float c, float kq,
+                                                float thr, bool tail, int rows_valid, unsigned row_base, int t,
+                                                const PropArgs& A) {
+    if (tail) {
+        asm volatile("; tail tile" ::: "memory");
+        mask_tail_rows(S, Sw, h, rows_valid);
+    }
+    float E[16];
+    float l0 = 0.0f, l1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        l0 += __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], c, -mc));
+        l1 += __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], c, -mc));
+        E[r] = __builtin_fmaf(Sw[r], c, -kq);
+        E[r + 1] = __builtin_fmaf(Sw[r + 1], c, -kq);
+    }
+    lsum += l0 + l1;
+    if (__any(max16v(E) >= thr)) {
+        asm volatile("; top-k candidates" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (E[r] >= thr && E[r] > -1.0e29f) {   // the second test drops masked padding rows
+                const unsigned idx = atomicAdd(&A.tk_cnt[t], 1u);
+                if (idx < (unsigned)kTopkCap)
+                    A.tk_cand[(size_t)t * kTopkCap + idx] = make_uint2(__float_as_uint(E[r]), row_base + acc_row(r, h));
+            }
+        }
+    }
+}
+
+template <bool PROB, bool LAB_LO, int MODE>
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArgs A) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kRing * kLdsBuf];
 
@@ -346,8 +445,18 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
 
         asm volatile("" : "+v"(kq1), "+v"(kq2));   // keep the f64 derivation out of the tile loop
 
+        TopkList lst;            // MODE 1 only
+        float tk_thr = 3.0e38f;  // MODE 2 only
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < kTopkMax; ++i) lst.v[i] = -3.0e38f;
+        }
         ColState st;
         st.m = kNegBig;
+        if (MODE == 2) {
+            st.m = A.tk_m[t_ld];
+            if (t < A.HW) tk_thr = A.tk_thr[t];
+        }
         st.l = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st.Y[r] = 0.0f;
@@ -430,7 +539,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             // ---- scores(p) ----
             if (have_st) stage_issue(b_st);
             LabFrag<LAB_LO> lab;
-            lab.load(lb, lane);
+            if (MODE == 0) lab.load(lb, lane);
             STAMP_AT(1);   // 1: issue of the LDS-DMA pieces + label reads
             f32x16 S, Sw;
             tile_scores<PROB>(lb, j, h, Bt, sparse ? Bx2 : Bx1, fr, S, Sw);
@@ -441,7 +550,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             fr.prefetch_lo(smem + b_nxt * kLdsBuf, j, h);   // first fragments of tile p+1 (harmless when p+1 == n_steps)
             STAMP_AT(4);   // 4: prefetch issue   (5: max + rescale decision, 6: exps + sums inside tile_softmax)
             const bool tail = ragged && ctile == TPF - 1;
-            tile_softmax<PROB, LAB_LO>(lab, h, S, Sw, st, c, kq, tail, rows_last STAMP_PASS);
+            if (MODE == 0) {
+                tile_softmax<PROB, LAB_LO>(lab, h, S, Sw, st, c, kq, tail, rows_last STAMP_PASS);
+            } else if (MODE == 1) {
+                tile_topk_pass1(S, Sw, st.m, lst, h, c, kq, tail, rows_last);
+            } else {
+                tile_topk_pass2(S, Sw, st.m * c, st.l, h, c, kq, tk_thr, tail, rows_last,
+                                (unsigned)(cn * A.HWp + ctile * kTileR), t, A);
+            }
             STAMP_AT(7);   // 7: pack + label MFMAs
             fr.prefetch_hi(smem + b_nxt * kLdsBuf, j, h);
             stage_wait();   // this wave's pieces of tile p+2 have landed (issued a whole step ago)
@@ -467,18 +583,28 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
                 atomicAdd(&A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + k], tsum[k]);
 #endif
 
-        // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
-        const float lsum = half_sum(st.l);
-        float* part = A.part + (((size_t)blockIdx.x * A.map.max_parts + (tt - tt_first)) * (2 + A.d)) * kBT
+        // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns (dense); (m, 2 x kTopkMax group maxima)
+        // in top-k pass 1; (m, l) in top-k pass 2 ----
+        float* part = A.part + (((size_t)blockIdx.x * A.map.max_parts + (tt - tt_first)) * A.part_rows) * kBT
                       + wave * kColsPerWave + j;
-        if (h == 0) {
-            part[0] = st.m;
-            part[kBT] = lsum;
-        }
+        if (MODE == 1) {
+            const float mm = half_max(st.m);
+            if (h == 0) part[0] = mm;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cls = acc_row(r, h);
-            if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
+            for (int i = 0; i < kTopkMax; ++i) part[(size_t)(1 + h * kTopkMax + i) * kBT] = lst.v[i];
+        } else {
+            const float lsum = half_sum(st.l);
+            if (h == 0) {
+                part[0] = st.m;
+                part[kBT] = lsum;
+            }
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cls = acc_row(r, h);
+                    if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
+                }
+            }
         }
     }
 }

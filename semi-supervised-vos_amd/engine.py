@@ -121,7 +121,8 @@ class PropagationEngine:
     # -- stateless operator -----------------------------------------------------------------------
     def predict(self, ref, target, ref_label, frame_idx, frame_range, ref_num, temperature, sigma1, sigma2,
                 probability_propagation):
-        """The reference's predict() (src/model/predict.py:19-71) with the weight matrices given by their sigmas."""
+        """The reference's predict() (src/model/predict.py:19-71) with the weight matrices given by their sigmas.
+        An engine created with topk=k applies the top-k variant (label mode only)."""
         T = ref.shape[0]
         d = ref_label.shape[0]
         ref = ref.contiguous()

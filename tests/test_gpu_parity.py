@@ -183,3 +183,54 @@ def test_state_errors(vos, dev):
     with pytest.raises(vos.VospropError):
         eng.begin_video(big)                                   # d = 41 > VOSPROP_MAX_CLASSES
     eng.close()
+
+
+# ---- top-k variant: not in the reference; checked against the oracle's restatement and
+# ---- through the identity  k >= N*HW  ==  dense ------------------------------------------------------------------
+@pytest.mark.parametrize('Hd,Wd,T,d,fi,k', [
+    (12, 20, 10, 4, 9, 20),      # N = 9, k = 20 (BASELINE config 3's k)
+    (12, 20, 21, 3, 20, 5),      # both sigma branches, k = 5
+    (5, 7, 4, 5, 3, 32),         # ragged map, k = 32 < N*HW = 105
+    (30, 54, 6, 4, 5, 20),       # config-1 map, N = 5
+])
+def test_topk_vs_oracle(vos, dev, Hd, Wd, T, d, fi, k):
+    feats, oh = _random_case(4321 + Hd * Wd + k, Hd, Wd, T, d)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, topk=k)
+    wd, ws = vo.get_spatial_weight((Hd, Wd), 8.0), vo.get_spatial_weight((Hd, Wd), 21.0)
+    fd, ld = torch.from_numpy(feats).to(dev), torch.from_numpy(oh).to(dev)
+    got = eng.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 40, 9, 1.0, 8.0, 21.0, False).cpu().numpy()
+    want = vo.predict(feats[:fi], feats[fi], oh[:, :fi], wd, ws, fi, 40, 9, 1.0, False, topk=k).numpy()
+    dense = vo.predict(feats[:fi], feats[fi], oh[:, :fi], wd, ws, fi, 40, 9, 1.0, False).numpy()
+    assert np.any(np.abs(want - dense) > 1e-4), 'test would not see a missing top-k'
+    # the candidates' weights are exact f32 here (no bf16 packing on this path): tighter than the dense tolerance
+    assert np.max(np.abs(got - want)) <= 2e-4 * max(1.0, want.max()) , np.max(np.abs(got - want))
+    eng.close()
+
+
+def test_topk_covering_everything_equals_dense(vos, dev):
+    Hd, Wd, T, d, fi = 4, 4, 3, 3, 2                      # N*HW = 32 = k
+    feats, oh = _random_case(99, Hd, Wd, T, d)
+    fd, ld = torch.from_numpy(feats).to(dev), torch.from_numpy(oh).to(dev)
+    e_k = vos.PropagationEngine(Hd, Wd, device=0, topk=32)
+    e_d = vos.PropagationEngine(Hd, Wd, device=0)
+    a = e_k.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 40, 9, 1.0, 8.0, 21.0, False).cpu().numpy()
+    b = e_d.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 40, 9, 1.0, 8.0, 21.0, False).cpu().numpy()
+    assert np.max(np.abs(a - b)) <= 4e-3 * b.max()
+    e_k.close(); e_d.close()
+
+
+def test_topk_rollout_vs_oracle(vos, dev):
+    case = gin.ROLLOUT_CASES[0]
+    ann, feats = gin.rollout_annotation(case), bf16_round(gin.rollout_features(case))
+    H, W = case['image_hw']
+    Hd, Wd = vos.feature_map_size(H, W)
+    _, want = vo.rollout(ann, feats, case['range'], 5, 1.0, 8.0, 21.0, False, topk=20)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=5, frame_range=case['range'], topk=20)
+    eng.begin_video(ann)
+    fd = torch.from_numpy(feats).to(dev)
+    masks = [eng.step(fd[t])[1] for t in range(feats.shape[0])][1:]
+    got = torch.stack(masks).cpu().numpy()
+    assert np.mean(got != want) <= 0.005
+    eng.close()
+    with pytest.raises(vos.VospropError):
+        vos.PropagationEngine(Hd, Wd, device=0, topk=20, probability=True)      # label-propagation mode only
