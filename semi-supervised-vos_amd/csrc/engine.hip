@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -14,6 +15,7 @@
 #include "aux_kernels.h"
 #include "common.h"
 #include "prop_bf16.h"
+#include "prop_bf16_v5.h"
 
 using namespace vosprop;
 
@@ -212,6 +214,13 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream
     const dim3 grid(lp.grid), block(kWaves * 64);
     if (mode == 1) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 1>), grid, block, 0, s, a); return; }
     if (mode == 2) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 2>), grid, block, 0, s, a); return; }
+    // prop_bf16_v5_kernel (one wave per SIMD, inline-asm MFMAs, row-interleaved softmax) is correct but still slower than the
+    // 8-wave kernel (336 vs 274 us at 480p); it is kept selectable for the next round's work
+    static const bool use_v5 = getenv("VOSPROP_V5") != nullptr;
+    if (!lp.prob && !lp.lab_lo && use_v5) {
+        hipLaunchKernelGGL(prop_bf16_v5_kernel, grid, dim3(kW5 * 64), 0, s, a);
+        return;
+    }
     if (lp.prob) {
         if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<true, true, 0>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((prop_bf16_kernel<true, false, 0>), grid, block, 0, s, a);

@@ -532,6 +532,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
         AFrag<PROB> fr;
         fr.prefetch(smem, j, h);
         int b_cur = 0, b_nxt = 1, b_st = 2;
+#ifndef VOSPROP_PRIO_MODE
+#define VOSPROP_PRIO_MODE 2   // 2 = score (MFMA) burst at priority 1: -3.5 % measured; 1 = younger wave group at priority 1: null; 0 = off
+#endif
+        if (VOSPROP_PRIO_MODE == 1 && grpB) __builtin_amdgcn_s_setprio(1);
         for (int p = 0; p < n_steps; ++p) {
             const bool have_st = (VOSPROP_ABLATE & 4) ? false : (p + 2 < n_steps);
             const unsigned char* lb = smem + b_cur * kLdsBuf;
@@ -542,7 +546,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             if (MODE == 0) lab.load(lb, lane);
             STAMP_AT(1);   // 1: issue of the LDS-DMA pieces + label reads
             f32x16 S, Sw;
+            if (VOSPROP_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
             tile_scores<PROB>(lb, j, h, Bt, sparse ? Bx2 : Bx1, fr, S, Sw);
+            if (VOSPROP_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(0);
             STAMP_AT(2);   // 2: MFMA chain
             if (!(VOSPROP_ABLATE & 8)) __syncthreads();
             STAMP_AT(3);   // 3: barrier 1

@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--scale', type=float, default=0.25)
     ap.add_argument('--prob', action='store_true')
+    ap.add_argument('--stateful', action='store_true', help='time the begin_video/step path (the dense one-hot kernel)')
     args = ap.parse_args()
     vos = importlib.import_module('semi-supervised-vos_amd')
     dev = torch.device('cuda', 0)
@@ -32,8 +33,17 @@ def main():
     feats = (torch.randn(T, 256, Hd, Wd, generator=g) * args.scale).to(torch.bfloat16).to(dev)
     lab = torch.randint(0, args.d, (T, Hd * Wd), generator=g)
     oh = torch.zeros(args.d, T, Hd * Wd).scatter_(0, lab.unsqueeze(0), 1.0).to(dev)
-    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=args.ref_num)
-    out = eng.predict(feats[:fi], feats[fi], oh[:, :fi], fi, 40, args.ref_num, 1.0, 8.0, 21.0, args.prob)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=args.ref_num, probability=args.prob)
+    if args.stateful:
+        import numpy as np
+        ann = np.zeros((Hd * 8, Wd * 8), np.uint8)
+        ann[: Hd * 4, : Wd * 4] = args.d - 1
+        ann[Hd * 4:, Wd * 2: Wd * 6] = 1
+        eng.begin_video(ann)
+        for t in range(T):
+            out, _ = eng.step(feats[t])
+    else:
+        out = eng.predict(feats[:fi], feats[fi], oh[:, :fi], fi, 40, args.ref_num, 1.0, 8.0, 21.0, args.prob)
     torch.cuda.synchronize()
     us = eng.time_last_propagation(args.iters)
     st = eng.last_stats()
