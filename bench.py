@@ -87,6 +87,22 @@ def cpu_baseline(wl, cfg, model_state, feats_hist, labels_hist_cls, ann, frames_
                       f'{T0 + 1}..{T0 + n_time}, N={wl["ref_num"]}, fp32, torch {threads} threads'}
 
 
+def mask_parity(wl, cfg, ann, feats, gpu_masks, n_frames=7):
+    """'mask IoU delta vs CPU ref' (BASELINE.json metric): the first frames of the bench clip propagated by the oracle on the
+    host from the SAME encoder features the GPU used, compared with the masks the engine produced for those frames."""
+    from oracle import vos_oracle as vo
+    n = min(n_frames, feats.shape[0])
+    topk = wl['topk']
+    _, want = vo.rollout(ann, feats[:n].numpy(), cfg['frame_range'], wl['ref_num'], cfg['temperature'], cfg['sigma1'],
+                         cfg['sigma2'], False, topk=topk)
+    got = np.stack(gpu_masks[1:n])
+    d = int(ann.max()) + 1
+    iou = vo.mask_iou_per_object(want, got, d)
+    return {'frames': n - 1, 'pixels_differing': float(np.mean(got != want)), 'per_object_iou': [round(v, 5) for v in iou],
+            'iou_delta': round(1.0 - min(iou), 5),
+            'what': 'engine masks vs oracle (torch-CPU restatement of the reference) on identical bf16 encoder features'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -131,7 +147,7 @@ def main():
                                 topk=wl['topk'])
     eng.begin_video(ann)
 
-    keep_feats, keep_cls = [], []
+    keep_feats, keep_cls, keep_masks = [], [], []
 
     B = max(1, args.encoder_batch)
     feat_buf = {'f': None, 'pos': 0}
@@ -153,6 +169,7 @@ def main():
         if keep:
             keep_feats.append(feats.float().cpu())
             keep_cls.append(None if pred is None else pred.argmax(0).cpu())
+            keep_masks.append(None if mask is None else mask.cpu().numpy())
         return mask
 
     fi = 0
@@ -222,6 +239,7 @@ def main():
             cls_hist = torch.stack([cls0] + [c for c in keep_cls[1:]], 0)
             frames_cpu = clip[0:6].float().cpu().contiguous()
             out['cpu_baseline'] = cpu_baseline(wl, cfg, model_state, fh, cls_hist, ann, frames_cpu)
+            out['mask_parity'] = mask_parity(wl, cfg, ann, fh, keep_masks)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))
