@@ -92,6 +92,12 @@ const char* vosprop_last_error(const vosprop_ctx* ctx);
  * ceil(H/8)==feat_h, ceil(W/8)==feat_w and d <= VOSPROP_MAX_CLASSES. */
 int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H, int W, int* d_out);
 
+/* Same, for the strategies whose feature map is not ceil(H/8) x ceil(W/8) of the output image (reference
+ * prepare_first_frame branches '2-scale' / 'hor-2-scale' / '3-scale', src/model/predict.py:137-153) or whose first labels are
+ * transformed (flips, :130-135): the caller passes the already down-sampled class map (feat_h x feat_w, uint8), the class
+ * count d and the size (out_h, out_w) the masks of vosprop_step are up-sampled to. */
+int vosprop_begin_video_labels(vosprop_ctx* ctx, const uint8_t* cls_lowres_host, int d, int out_h, int out_w);
+
 /* One iteration of the `inference_single` loop body after the encoder
  * (reference src/utils/inference_utils.py:33-75):
  *   frame 0  : stores the features in the ring (:36, feats_history = model(input)); no outputs.

@@ -120,13 +120,19 @@ class VideoState:
     """The per-video state `inference_single` keeps in module globals
     (src/utils/inference_utils.py:25,33-48)."""
 
-    def __init__(self, first_label, sigma1=8.0, sigma2=21.0, probability_propagation=False):
+    def __init__(self, first_label, sigma1=8.0, sigma2=21.0, probability_propagation=False, map_scale=None,
+                 label_transform=None, out_hw=None):
+        """map_scale / label_transform / out_hw: the multi-branch strategies' variants of prepare_first_frame
+        (predict.py:130-153) - scaled label map, flipped first label, fixed output size (3-scale)."""
         label = np.asarray(first_label)
         self.H, self.W = label.shape
-        self.H_d, self.W_d = feature_map_size(self.H, self.W)
+        k = SCALE if map_scale is None else SCALE * map_scale       # predict.py:138-139,148-149
+        self.H_d, self.W_d = int(np.ceil(self.H * k)), int(np.ceil(self.W * k))
         self.d = int(label.max()) + 1                                # predict.py:113
         self.prob = bool(probability_propagation)
-        self.label_history = get_labels(label.astype(np.int64), self.d, self.H, self.W, self.H_d, self.W_d)
+        lab0 = label if label_transform is None else np.ascontiguousarray(label_transform(label))
+        self.label_history = get_labels(lab0.astype(np.int64), self.d, self.H, self.W, self.H_d, self.W_d)
+        self.out_hw = (self.H, self.W) if out_hw is None else tuple(out_hw)
         if self.prob:
             self.w_dense = self.w_sparse = None                      # predict.py:117-118
         else:
@@ -156,9 +162,10 @@ def rollout_step(state, features, frame_range, ref_num, temperature, topk=0):
     state.label_history = torch.cat((state.label_history, new_label), 1)           # :71
     state.feats_history = torch.cat((state.feats_history, features), 0)            # :72
     up = torch.nn.functional.interpolate(pred.view(1, state.d, state.H_d, state.W_d),
-                                         size=(state.H, state.W), mode='nearest')  # :74
+                                         size=state.out_hw, mode='nearest')         # :74
     mask = torch.argmax(up, 1)[0]                                                   # :75
     state.frame_idx += 1
+    state.last_upsampled = up
     return pred, mask
 
 
@@ -174,6 +181,71 @@ def rollout(first_label, feats, frame_range=40, ref_num=9, temperature=1.0, sigm
             preds.append(p.numpy())
             masks.append(m.numpy().astype(np.uint8))
     return np.stack(preds), np.stack(masks)
+
+
+# ---- multi-branch strategies (src/utils/inference_utils.py:90-595) ------------------------------------------------
+REDUCTIONS = {'maximum': torch.maximum, 'minimum': torch.minimum, 'mean': lambda x, y: (x + y) / 2.0}   # :18-20
+
+# strategy -> (first-label transform of branch 2, branch 2 uses the scaled map, un-flip applied to branch 2's output)
+TWO_BRANCH = {
+    'hor-flip': (np.fliplr, False, 'fliplr'),       # :90-187; prepare_first_frame 'hor-flip' predict.py:130-132
+    'vert-flip': (np.flipud, False, 'fliplr'),      # :196-298; un-flipped with fliplr all the same (:282)
+    '2-scale': (None, True, None),                  # :300-413
+    'hor-2-scale': (None, True, 'hflip'),           # flip_pred=True (:389-390); labels are NOT mirrored (:326)
+    'multimodel': (None, False, None),              # :416-511
+}
+
+
+def fuse_two(up_a, up_b, prob, reduction, unflip):
+    """Per-frame fusion.  up_* are the up-sampled predictions (1,d,H,W).  Label mode (:158-178): argmax each, un-flip
+    the second CLASS MAP, element-wise maximum of the class indices.  Probability mode: torch.fliplr acts on the
+    (1,d,H,W) tensor, i.e. reverses the class axis (:166); hflip reverses W (:390); reduce, cast to half, argmax."""
+    if not prob:
+        a, b = torch.argmax(up_a, 1)[0], torch.argmax(up_b, 1)[0]
+        if unflip == 'fliplr':
+            b = torch.fliplr(b)
+        elif unflip == 'hflip':
+            b = b.flip(-1)
+        return torch.maximum(a, b)
+    b = up_b
+    if unflip == 'fliplr':
+        b = torch.fliplr(b)
+    elif unflip == 'hflip':
+        b = b.flip(-1)
+    return torch.argmax(REDUCTIONS[reduction](up_a, b).half(), 1)[0]
+
+
+def rollout_two_branch(strategy, first_label, feats_a, feats_b, scale=None, reduction='mean', frame_range=40, ref_num=9,
+                       temperature=1.0, sigma1=8.0, sigma2=21.0, probability_propagation=False):
+    """The two-chain strategies for one video with the encoder outputs supplied.  -> masks (T-1,H,W) u8."""
+    tf, scaled, unflip = TWO_BRANCH[strategy]
+    sa = VideoState(first_label, sigma1, sigma2, probability_propagation)
+    sb = VideoState(first_label, sigma1, sigma2, probability_propagation, map_scale=scale if scaled else None,
+                    label_transform=tf)
+    masks = []
+    for t in range(feats_a.shape[0]):
+        pa, _ = rollout_step(sa, torch.as_tensor(feats_a[t:t + 1]), frame_range, ref_num, temperature)
+        pb, _ = rollout_step(sb, torch.as_tensor(feats_b[t:t + 1]), frame_range, ref_num, temperature)
+        if pa is not None:
+            m = fuse_two(sa.last_upsampled, sb.last_upsampled, probability_propagation, reduction, unflip)
+            masks.append(m.numpy().astype(np.uint8))
+    return np.stack(masks)
+
+
+def rollout_3_scale(first_label, feats_per_scale, scales, output_size=(480, 910), frame_range=40, ref_num=9,
+                    temperature=1.0, sigma1=8.0, sigma2=21.0, probability_propagation=False):
+    """:514-595: one chain per scale (label map ceil(H*0.125*s)), class maps at the fixed output size, maximum of the
+    three class maps (:594)."""
+    outs = []
+    for s, feats in zip(scales, feats_per_scale):
+        st = VideoState(first_label, sigma1, sigma2, probability_propagation, map_scale=s, out_hw=output_size)
+        masks = []
+        for t in range(feats.shape[0]):
+            p, m = rollout_step(st, torch.as_tensor(feats[t:t + 1]), frame_range, ref_num, temperature)
+            if p is not None:
+                masks.append(m.numpy().astype(np.int8))
+        outs.append(np.stack(masks))
+    return np.maximum(np.maximum(outs[0], outs[1]), outs[2]).astype(np.uint8)
 
 
 def eval_j(annotation, segmentation):

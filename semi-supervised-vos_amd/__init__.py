@@ -7,6 +7,7 @@ from . import _native
 from ._native import VospropError, build
 from .engine import PropagationEngine, feature_map_size, sample_frames_list, PREC_BF16, PREC_F32
 from .config import Config
+from . import inference_utils  # noqa: E402,F401
 
 __all__ = ['Config', 'PropagationEngine', 'VospropError', 'build', 'feature_map_size', 'sample_frames_list',
            'PREC_BF16', 'PREC_F32']

@@ -467,6 +467,23 @@ const char* vosprop_last_error(const vosprop_ctx* ctx) { return ctx ? ctx->err.c
 
 int vosprop_frame_index(const vosprop_ctx* ctx) { return ctx && ctx->in_video ? ctx->frame_idx : -1; }
 
+static int begin_with_lowres(vosprop_ctx* ctx, const std::vector<uint8_t>& cls, int d, int H, int W) {
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(ctx->ring.cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
+    int rc = pack_labels_from_cls(ctx, ctx->ring.cls, ctx->ring.lab_hi, nullptr);
+    if (rc) return rc;
+    const size_t lab_slot_b = (size_t)ctx->tiles * 2 * 64 * 8 * sizeof(bf16_t);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ring.lab_lo, 0, lab_slot_b, nullptr));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    ctx->in_video = true;
+    ctx->frame_idx = 0;
+    ctx->d = d;
+    ctx->H = H;
+    ctx->W = W;
+    return VOSPROP_OK;
+}
+
 int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H, int W, int* d_out) {
     if (!ctx || !first_label_host || H < 1 || W < 1) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
     const int Hd = (int)std::ceil(H * 0.125), Wd = (int)std::ceil(W * 0.125);   // reference predict.py:109-110
@@ -481,21 +498,21 @@ int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H
         const int sy = nearest_src(y, H, Hd);
         for (int x = 0; x < Wd; ++x) cls[(size_t)y * Wd + x] = first_label_host[(size_t)sy * W + nearest_src(x, W, Wd)];
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipMemcpy(ctx->ring.cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
-    int rc = pack_labels_from_cls(ctx, ctx->ring.cls, ctx->ring.lab_hi, nullptr);
+    const int rc = begin_with_lowres(ctx, cls, d, H, W);
     if (rc) return rc;
-    const size_t lab_slot_b = (size_t)ctx->tiles * 2 * 64 * 8 * sizeof(bf16_t);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ring.lab_lo, 0, lab_slot_b, nullptr));
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    ctx->in_video = true;
-    ctx->frame_idx = 0;
-    ctx->d = d;
-    ctx->H = H;
-    ctx->W = W;
     if (d_out) *d_out = d;
     return VOSPROP_OK;
+}
+
+int vosprop_begin_video_labels(vosprop_ctx* ctx, const uint8_t* cls_lowres_host, int d, int out_h, int out_w) {
+    if (!ctx || !cls_lowres_host || out_h < 1 || out_w < 1 || d < 1) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
+    if (d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "more than VOSPROP_MAX_CLASSES classes");
+    std::vector<uint8_t> cls((size_t)ctx->HWp, 0);
+    for (int i = 0; i < ctx->HW; ++i) {
+        if (cls_lowres_host[i] >= d) return fail(ctx, VOSPROP_E_INVALID, "class index >= d in the label map");
+        cls[(size_t)i] = cls_lowres_host[i];
+    }
+    return begin_with_lowres(ctx, cls, d, out_h, out_w);
 }
 
 int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* pred_out_dev, uint8_t* mask_out_dev,

@@ -1,6 +1,8 @@
 """Input contract of the reference's InferenceDataset (src/utils/datasets.py:111-167) without torchvision:
 sorted video directories, sorted frames, JPEG -> RGB -> [0,1] CHW f32 -> ImageNet normalisation.
-Items are (tensor (3,H,W), video_name); the DataLoader's batch of 1 turns that into ((1,3,H,W), (name,))."""
+Items are (tensor (3,H,W), video_name); the DataLoader's batch of 1 turns that into ((1,3,H,W), (name,)).  The flip and
+2-scale strategies return a PAIR of tensors per frame (datasets.py:148-162): the frame and its mirrored / flipped /
+Lanczos-rescaled copy (PIL's ANTIALIAS is the old name of LANCZOS)."""
 from pathlib import Path
 
 import numpy as np
@@ -9,6 +11,7 @@ import torch.utils.data
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
+STRATEGIES = ('single', 'hor-flip', 'vert-flip', '2-scale', 'multimodel', 'hor-2-scale', '3-scale')
 _EXT = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.pgm', '.tif', '.tiff', '.webp')
 
 
@@ -33,8 +36,10 @@ def normalize_image(img):
 class InferenceDataset(torch.utils.data.Dataset):
     def __init__(self, root, transform=None, target_transform=None, disable=False, inference_strategy='single',
                  scale=None, videos=None):
-        if inference_strategy != 'single':
-            raise NotImplementedError(f"inference strategy '{inference_strategy}' is not built (SURVEY.md section 8f)")
+        if inference_strategy not in STRATEGIES:
+            raise ValueError(f"unknown inference strategy '{inference_strategy}'")
+        self.inference_strategy = inference_strategy
+        self.scale = scale
         vids = list_videos(root)
         if videos is not None:           # a shard: subset of the video names, reference order kept
             vids = {k: v for k, v in vids.items() if k in set(videos)}
@@ -45,8 +50,21 @@ class InferenceDataset(torch.utils.data.Dataset):
     def __getitem__(self, index):
         from io import BytesIO
         from PIL import Image
-        img = Image.open(BytesIO(self.img_bytes[index]))
-        return normalize_image(img), self.imgs[index][1]
+        from PIL import ImageOps
+        img = Image.open(BytesIO(self.img_bytes[index])).convert('RGB')
+        name = self.imgs[index][1]
+        normalized = normalize_image(img)
+        st = self.inference_strategy
+        if st == 'hor-flip':                                   # reference datasets.py:148-151
+            return (normalized, normalize_image(ImageOps.mirror(img))), name
+        if st == 'vert-flip':                                  # :152-155
+            return (normalized, normalize_image(ImageOps.flip(img))), name
+        if st in ('2-scale', 'hor-2-scale'):                   # :156-162: Lanczos resize to ceil(size * scale)
+            size2 = tuple(int(v) for v in np.ceil(np.array(img.size) * self.scale))
+            if st == 'hor-2-scale':
+                img = ImageOps.mirror(img)
+            return (normalized, normalize_image(img.resize(size2, Image.LANCZOS))), name
+        return normalized, name                                # single, multimodel, 3-scale
 
     def __len__(self):
         return len(self.imgs)

@@ -87,6 +87,18 @@ class PropagationEngine:
         self.d, self.H, self.W = d.value, lab.shape[0], lab.shape[1]
         return self.d
 
+    def begin_video_labels(self, cls_lowres, d, out_hw):
+        """Start a video from an already down-sampled class map (feat_h, feat_w) - the multi-scale / flip strategies.
+        Masks of step() are up-sampled to out_hw."""
+        lab = np.ascontiguousarray(np.asarray(cls_lowres), dtype=np.uint8)
+        if lab.shape != (self.feat_h, self.feat_w):
+            raise ValueError(f'label map must be ({self.feat_h},{self.feat_w}), got {lab.shape}')
+        rc = self._L.vosprop_begin_video_labels(self._ctx, lab.ctypes.data_as(ctypes.c_void_p), int(d), int(out_hw[0]),
+                                                int(out_hw[1]))
+        self._check(rc, 'vosprop_begin_video_labels')
+        self.d, self.H, self.W = int(d), int(out_hw[0]), int(out_hw[1])
+        return self.d
+
     @property
     def frame_index(self):
         return self._L.vosprop_frame_index(self._ctx)

@@ -14,7 +14,8 @@ import torch.utils.data
 
 from .config import Config
 from .datasets import InferenceDataset, list_videos
-from .inference_utils import inference_single
+from .inference_utils import (inference_2_scale, inference_3_scale, inference_hor_flip, inference_multimodel,
+                              inference_single, inference_ver_flip)
 from .sharding import shard_for_rank
 from .utils import load_model
 from .vos_net import VOSNet
@@ -89,9 +90,6 @@ def _launch_shards(gpus):
 def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
                            reduction, disable=False, encoder_dtype='bf16', shard=(0, 1), encoder_batch=16):
-    if inference_strategy != 'single':
-        raise NotImplementedError(f"inference strategy '{inference_strategy}' is not built yet (SURVEY.md section 8f); "
-                                  "'single' is the path this engine replaces")
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)
     if Config.DEVICE.type == 'cuda':
@@ -100,6 +98,12 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
     net = load_model(net, resume)
     dtype = _DTYPES[encoder_dtype] if Config.DEVICE.type == 'cuda' else None
     net.prepare_for_inference(Config.DEVICE, dtype)
+    additional = None
+    if inference_strategy == 'multimodel':      # reference src/inference.py:65-71
+        if not additional_resume:
+            raise click.UsageError("--inference-strategy multimodel needs --additional-model")
+        additional = load_model(VOSNet(model=additional_model_type), additional_resume)
+        additional.prepare_for_inference(Config.DEVICE, dtype)
 
     data_dir = str(Path(data) / 'JPEGImages/480p')
     videos = None
@@ -115,8 +119,22 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
     last_video = dataset.imgs[0][1]
     stats = {}
     with torch.no_grad():
-        inference_single(net, loader, len(dataset), annotation_dir, last_video, save, sigma_1, sigma_2, frame_range,
-                         ref_num, temperature, probability_propagation, disable, encoder_dtype=dtype, stats=stats,
-                         encoder_batch=encoder_batch)
+        head = (loader, len(dataset), annotation_dir, last_video, save, sigma_1, sigma_2, frame_range, ref_num,
+                temperature, probability_propagation)
+        opts = dict(encoder_dtype=dtype, stats=stats, encoder_batch=encoder_batch)
+        if inference_strategy == 'single':
+            inference_single(net, *head, disable, **opts)
+        elif inference_strategy == 'hor-flip':
+            inference_hor_flip(net, *head, reduction, disable, **opts)
+        elif inference_strategy == 'vert-flip':
+            inference_ver_flip(net, *head, reduction, disable, **opts)
+        elif inference_strategy == '2-scale':
+            inference_2_scale(net, *head, scale, reduction, False, disable, **opts)
+        elif inference_strategy == 'multimodel':
+            inference_multimodel(net, additional, *head, reduction, disable, **opts)
+        elif inference_strategy == 'hor-2-scale':
+            inference_2_scale(net, *head, scale, reduction, True, disable, **opts)
+        elif inference_strategy == '3-scale':
+            inference_3_scale(net, *head, scale, disable, **opts)
     stats['shard'] = list(shard)
     print(json.dumps({'vosprop_stats': stats}))

@@ -125,7 +125,17 @@ def prepare_first_frame(curr_video, save_prediction, annotation, sigma1=8, sigma
         save_path = os.path.join(save_prediction, curr_video)
         os.makedirs(save_path, exist_ok=True)
         first_annotation.save(os.path.join(save_path, '00000.png'))
-    if inference_strategy != 'single':
-        raise NotImplementedError(f"inference strategy '{inference_strategy}' is a later row of the scope table "
-                                  "(SURVEY.md section 8f); only 'single' is built")
-    return label_1hot, d, palette, weight_dense, weight_sparse
+    if inference_strategy == 'hor-flip':
+        return label_1hot, get_labels(torch.fliplr(label), d, H, W, H_d, W_d), d, palette, weight_dense, weight_sparse
+    if inference_strategy == 'ver-flip':        # the name the reference's loop passes (inference_utils.py:219)
+        return label_1hot, get_labels(torch.flipud(label), d, H, W, H_d, W_d), d, palette, weight_dense, weight_sparse
+    if inference_strategy in ('2-scale', 'hor-2-scale', '3-scale'):
+        H_d_2 = int(np.ceil(H * Config.SCALE * scale))
+        W_d_2 = int(np.ceil(W * Config.SCALE * scale))
+        weight_dense_2 = get_spatial_weight((H_d_2, W_d_2), sigma1) if not probability_propagation else None
+        weight_sparse_2 = get_spatial_weight((H_d_2, W_d_2), sigma2) if not probability_propagation else None
+        label_1hot_2 = get_labels(label, d, H, W, H_d_2, W_d_2)
+        if inference_strategy == '3-scale':     # predict.py:145-153: the scaled set replaces the plain one
+            return label_1hot_2, d, palette, weight_dense_2, weight_sparse_2
+        return (label_1hot, label_1hot_2), d, palette, (weight_dense, weight_dense_2), (weight_sparse, weight_sparse_2)
+    return label_1hot, d, palette, weight_dense, weight_sparse      # 'single', 'multimodel' (:142-144) and anything else

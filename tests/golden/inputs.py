@@ -135,6 +135,68 @@ def rollout_features(case):
     return feats.astype(np.float32)
 
 
+# ---- multi-branch strategies (G7): one clip, the encoder replaced by seeded features per (branch, map size) ----
+STRATEGY_CASE = dict(name='g7', seed=401, video='clipS', C=256, image_hw=(96, 160), T=19, n_obj=3, scale=0.25, drift=0.3,
+                     range=40, ref_num=9, sigma1=8.0, sigma2=21.0, temperature=1.0, scale2=1.15, out3=(480, 910))
+STRATEGIES_2 = ('hor-flip', 'vert-flip', '2-scale', 'hor-2-scale', 'multimodel')
+# (strategy, probability, fusion) combinations stored as goldens
+STRATEGY_RUNS = [(s, False, 'mean') for s in STRATEGIES_2] + [(s, True, 'mean') for s in STRATEGIES_2] + \
+                [('hor-flip', True, 'maximum'), ('2-scale', True, 'minimum')]
+
+
+def strategy_map_hw(case, scale=None):
+    H, W = case['image_hw']
+    k = 0.125 if scale is None else 0.125 * scale
+    return int(np.ceil(H * k)), int(np.ceil(W * k))
+
+
+def strategy_input_hw(case, strategy, branch):
+    """Size of the image the dataset hands to the encoder for a branch (reference datasets.py:156-162)."""
+    H, W = case['image_hw']
+    if strategy in ('2-scale', 'hor-2-scale') and branch == 1:
+        return int(np.ceil(H * case['scale2'])), int(np.ceil(W * case['scale2']))
+    return H, W
+
+
+def strategy_features(case, branch_seed, map_hw, flip=None):
+    """(T,C,Hd,Wd) f32 features of one chain: the clip's class layout (nearest down-sample of the annotation onto the
+    chain's map, mirrored / flipped for the flipped branches) as prototypes + temporally correlated noise."""
+    H, W = case['image_hw']
+    Hd, Wd = map_hw
+    rs = np.random.RandomState(case['seed'] + 17 * branch_seed)
+    C, T = case['C'], case['T']
+    m = rollout_annotation(case)
+    if flip == 'w':
+        m = m[:, ::-1]
+    elif flip == 'h':
+        m = m[::-1, :]
+    md = m[(np.arange(Hd) * H) // Hd][:, (np.arange(Wd) * W) // Wd]
+    protos = np.random.RandomState(case['seed']).standard_normal((case['n_obj'] + 1, C)).astype(np.float32)
+    noise = rs.standard_normal((C, Hd, Wd)).astype(np.float32)
+    feats = np.empty((T, C, Hd, Wd), dtype=np.float32)
+    for t in range(T):
+        mdt = np.roll(np.roll(md, (t // 2) * (-1 if flip == 'w' else 1), axis=1), (t // 5) * (-1 if flip == 'h' else 1),
+                      axis=0)
+        base = protos[mdt].transpose(2, 0, 1)
+        noise = np.sqrt(1 - case['drift'] ** 2) * noise + case['drift'] * rs.standard_normal((C, Hd, Wd))
+        feats[t] = (0.6 * base + 1.0 * noise) * case['scale']
+    return feats.astype(np.float32)
+
+
+def strategy_branch_features(case, strategy):
+    """-> [features of branch 0, features of branch 1] for a two-branch strategy."""
+    flip = {'hor-flip': 'w', 'vert-flip': 'h', 'hor-2-scale': 'w'}.get(strategy)
+    scaled = strategy in ('2-scale', 'hor-2-scale')
+    a = strategy_features(case, 0, strategy_map_hw(case))
+    b = strategy_features(case, 1, strategy_map_hw(case, case['scale2'] if scaled else None), flip)
+    return [a, b]
+
+
+def three_scale_features(case):
+    scales = (0.9, 1.0, case['scale2'])
+    return scales, [strategy_features(case, 10 + i, strategy_map_hw(case, s)) for i, s in enumerate(scales)]
+
+
 def onehot_indices(seed=5, n=40, d=5):
     return np.random.RandomState(seed).randint(0, d, size=n).astype(np.int64)
 

@@ -151,6 +151,67 @@ def main():
                 out[f'{tag}_preds'] = np.stack(preds)           # (T-1, d, HW)
                 out[f'{tag}_masks'] = np.stack(masks)           # (T-1, H, W) u8
 
+    # ---- G7: the multi-branch strategies (src/utils/inference_utils.py:90-595) with seeded encoder outputs ----------
+    from PIL import Image
+    case = gin.STRATEGY_CASE
+    H, W = case['image_hw']
+    T = case['T']
+
+    class FakeEncoder:
+        """Returns the pre-generated features of (frame, branch); checks that the map size a stride-8 encoder would
+        produce for the input it is handed equals the size of those features."""
+
+        def __init__(self, feats_by_call):
+            self.feats, self.i = feats_by_call, 0
+
+        def __call__(self, x):
+            f = self.feats[self.i]
+            self.i += 1
+            assert (int(np.ceil(x.shape[2] / 8)), int(np.ceil(x.shape[3] / 8))) == f.shape[-2:], (x.shape, f.shape)
+            return torch.from_numpy(f[None].copy())
+
+    def read_masks(save_dir):
+        return np.stack([np.asarray(Image.open(save_dir / case['video'] / f'{i:05d}.png')).astype(np.uint8)
+                         for i in range(1, T)])
+
+    for (strategy, prob, fusion) in gin.STRATEGY_RUNS:
+        fa, fb = gin.strategy_branch_features(case, strategy)
+        with tempfile.TemporaryDirectory() as td:
+            td = Path(td)
+            gin.write_rollout_annotation(case, td / 'ann')
+            sizes = [gin.strategy_input_hw(case, strategy, b) for b in (0, 1)]
+            if strategy == 'multimodel':
+                loader = [(torch.zeros(1, 3, H, W), (case['video'],)) for _ in range(T)]
+                m0, m1 = FakeEncoder(list(fa)), FakeEncoder(list(fb))
+            else:
+                loader = [([torch.zeros(1, 3, *sizes[0]), torch.zeros(1, 3, *sizes[1])], (case['video'],)) for _ in range(T)]
+                m0 = FakeEncoder([f for t in range(T) for f in (fa[t], fb[t])])      # model(input_l); model(input_r)
+            head = (loader, T, td / 'ann', case['video'], str(td / 'save'), case['sigma1'], case['sigma2'], case['range'],
+                    case['ref_num'], case['temperature'], prob)
+            if strategy == 'hor-flip':
+                riu.inference_hor_flip(m0, *head, fusion, True)
+            elif strategy == 'vert-flip':
+                riu.inference_ver_flip(m0, *head, fusion, True)
+            elif strategy == '2-scale':
+                riu.inference_2_scale(m0, *head, case['scale2'], fusion, False, True)
+            elif strategy == 'hor-2-scale':
+                riu.inference_2_scale(m0, *head, case['scale2'], fusion, True, True)
+            else:
+                riu.inference_multimodel(m0, m1, *head, fusion, True)
+            out[f"g7_{strategy}_{'prob_' + fusion if prob else 'label'}_masks"] = read_masks(td / 'save')
+
+    scales, f3 = gin.three_scale_features(case)
+    for prob in (False, True):
+        with tempfile.TemporaryDirectory() as td:
+            td = Path(td)
+            gin.write_rollout_annotation(case, td / 'ann')
+            loader = [(torch.zeros(1, 3, H, W), (case['video'],)) for _ in range(T)]
+            enc = FakeEncoder([f for fs in f3 for f in fs])                           # three sequential passes
+            riu.inference_3_scale(enc, loader, T, td / 'ann', case['video'], str(td / 'save'), case['sigma1'],
+                                  case['sigma2'], case['range'], case['ref_num'], case['temperature'], prob,
+                                  case['scale2'], True)
+            out[f"g7_3-scale_{'prob' if prob else 'label'}_masks"] = read_masks(td / 'save')
+
     # ---- index_to_onehot (src/utils/utils.py:59-68) -----------------------------------------
     idx = torch.from_numpy(gin.onehot_indices())
     out['onehot'] = index_to_onehot(idx, 5).numpy()

@@ -181,3 +181,100 @@ def test_cli_flags_match_the_reference():
     assert '-m' in opts['model'].opts and '-t' in opts['temperature'].opts and '-s' in opts['save'].opts
     assert list(opts['inference_strategy'].type.choices) == ['single', 'hor-flip', 'vert-flip', '2-scale', 'multimodel',
                                                              'hor-2-scale', '3-scale']
+
+
+def test_wrappers_keep_the_reference_signatures(vos):
+    """inference_hor_flip(model, loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2, frame_range, ref_num,
+    temperature, probability_propagation, reduction_str, disable) etc. - positional order of the reference."""
+    import inspect
+    iu = vos.inference_utils
+    base = ['inference_loader', 'total_len', 'annotation_dir', 'last_video', 'save', 'sigma_1', 'sigma_2', 'frame_range',
+            'ref_num', 'temperature', 'probability_propagation']
+    want = {
+        'inference_hor_flip': ['model'] + base + ['reduction_str', 'disable'],
+        'inference_ver_flip': ['model'] + base + ['reduction_str', 'disable'],
+        'inference_2_scale': ['model'] + base + ['scale', 'reduction_str', 'flip_pred', 'disable'],
+        'inference_multimodel': ['model', 'additional_model'] + base + ['reduction_str', 'disable'],
+        'inference_3_scale': ['model'] + base + ['scale', 'disable'],
+    }
+    for name, params in want.items():
+        got = list(inspect.signature(getattr(iu, name)).parameters)[:len(params)]
+        assert got == params, name
+
+
+@pytest.mark.parametrize('strategy', ['hor-flip', 'vert-flip', '2-scale', 'hor-2-scale', 'multimodel'])
+@pytest.mark.parametrize('prob,fusion', [(False, 'mean'), (True, 'mean'), (True, 'maximum'), (True, 'minimum')])
+def test_fusion_matches_the_oracle(vos, strategy, prob, fusion):
+    """fuse_two (device-agnostic torch) == the oracle's restatement of the reference's per-frame fusion, including the
+    class-axis fliplr of probability mode."""
+    from oracle import vos_oracle as vo
+    rs = np.random.RandomState(3)
+    d, H, W = 4, 6, 6            # square on purpose: fliplr of (1,d,H,W) with d != W would not even be an image flip
+    ua = torch.from_numpy(rs.uniform(size=(1, d, H, W)).astype(np.float32))
+    ub = torch.from_numpy(rs.uniform(size=(1, d, H, W)).astype(np.float32))
+    unflip = vo.TWO_BRANCH[strategy][2]
+    want = vo.fuse_two(ua, ub, prob, fusion, unflip).numpy()
+    spec = vos.inference_utils._TWO_BRANCH[strategy]
+    assert spec['unflip'] == unflip and spec['scaled'] == vo.TWO_BRANCH[strategy][1]
+    if prob:
+        got = vos.inference_utils.fuse_two(ua, ub, True, fusion, spec['unflip'])
+    else:
+        got = vos.inference_utils.fuse_two(ua.argmax(1)[0].to(torch.uint8), ub.argmax(1)[0].to(torch.uint8), False, fusion,
+                                           spec['unflip'])
+    assert np.array_equal(got.numpy(), want)
+
+
+def test_lowres_class_map_equals_get_labels(goldens):
+    from oracle import vos_oracle as vo
+    import inputs as gin
+    m = gin.g3_mask()
+    H, W = m.shape
+    for (hd, wd) in [(30, 54), (35, 62), (27, 49)]:
+        cls = importlib.import_module('semi-supervised-vos_amd').inference_utils.lowres_class_map(m, hd, wd)
+        oh = vo.get_labels(m.astype(np.int64), int(m.max()) + 1, H, W, hd, wd)[:, 0].numpy()
+        assert np.array_equal(oh.argmax(0).reshape(hd, wd), cls) and np.all(oh.sum(0) == 1)
+
+
+def test_dataset_strategy_pairs(tmp_path, vos):
+    """hor-flip / vert-flip / 2-scale / hor-2-scale items are (frame, transformed frame) pairs (reference datasets.py:148-162)."""
+    from PIL import Image
+    ds_mod = importlib.import_module('semi-supervised-vos_amd.datasets')
+    rs = np.random.RandomState(0)
+    (tmp_path / 'v').mkdir()
+    img = rs.randint(0, 255, size=(24, 40, 3)).astype(np.uint8)
+    Image.fromarray(img).save(tmp_path / 'v' / '00000.png')
+    base, _ = ds_mod.InferenceDataset(tmp_path)[0]
+    (a, b), name = ds_mod.InferenceDataset(tmp_path, inference_strategy='hor-flip')[0]
+    assert name == 'v' and torch.equal(a, base) and torch.equal(b, base.flip(-1))
+    (a, b), _ = ds_mod.InferenceDataset(tmp_path, inference_strategy='vert-flip')[0]
+    assert torch.equal(b, base.flip(-2))
+    (a, b), _ = ds_mod.InferenceDataset(tmp_path, inference_strategy='2-scale', scale=1.15)[0]
+    assert torch.equal(a, base) and tuple(b.shape) == (3, 28, 46)
+    (a, b2), _ = ds_mod.InferenceDataset(tmp_path, inference_strategy='hor-2-scale', scale=1.15)[0]
+    assert tuple(b2.shape) == (3, 28, 46) and not torch.equal(b, b2)
+    x, _ = ds_mod.InferenceDataset(tmp_path, inference_strategy='3-scale', scale=1.15)[0]
+    assert torch.equal(x, base)
+    with pytest.raises(ValueError):
+        ds_mod.InferenceDataset(tmp_path, inference_strategy='diagonal')
+
+
+def test_prepare_first_frame_strategy_forms(tmp_path, vos):
+    """Return arities / shapes of prepare_first_frame for every strategy (reference predict.py:128-155)."""
+    import inputs as gin
+    P = importlib.import_module('semi-supervised-vos_amd.predict')
+    vos.Config.DEVICE = torch.device('cpu')
+    case = gin.STRATEGY_CASE
+    ann = gin.write_rollout_annotation(case, tmp_path)
+    H, W = case['image_hw']
+    lab, d, pal, wd, ws = P.prepare_first_frame('v', None, ann)
+    assert tuple(lab.shape) == (d, 1, 12 * 20) and wd.sigma == 8 and ws.sigma == 21
+    l, r, d2, pal, wd, ws = P.prepare_first_frame('v', None, ann, inference_strategy='hor-flip')
+    assert tuple(r.shape) == tuple(l.shape)
+    l, r, *_ = P.prepare_first_frame('v', None, ann, inference_strategy='ver-flip')
+    assert tuple(r.shape) == tuple(l.shape)
+    (l, l2), d, pal, (wd, wd2), (ws, ws2) = P.prepare_first_frame('v', None, ann, inference_strategy='2-scale', scale=1.15)
+    assert tuple(l2.shape) == (d, 1, 14 * 23) and wd2.shape == (14, 23) and wd.shape == (12, 20)
+    l3, d, pal, wd3, ws3 = P.prepare_first_frame('v', None, ann, inference_strategy='3-scale', scale=0.9,
+                                                  probability_propagation=True)
+    assert tuple(l3.shape) == (d, 1, 11 * 18) and wd3 is None and ws3 is None
+    assert len(P.prepare_first_frame('v', None, ann, inference_strategy='multimodel')) == 5

@@ -100,3 +100,29 @@ def test_eval_j():
     b = np.zeros((4, 5), bool); b[2:4, 2:5] = True
     assert vo.eval_j(a, b) == pytest.approx(2 / 10)
     assert vo.eval_j(np.zeros((3, 3)), np.zeros((3, 3))) == 1.0
+
+
+@pytest.mark.parametrize('strategy,prob,fusion', gin.STRATEGY_RUNS)
+def test_two_branch_strategies(goldens, strategy, prob, fusion):
+    """oracle.rollout_two_branch against the reference's inference_hor_flip / _ver_flip / _2_scale / _multimodel."""
+    case = gin.STRATEGY_CASE
+    fa, fb = gin.strategy_branch_features(case, strategy)
+    masks = vo.rollout_two_branch(strategy, gin.rollout_annotation(case), fa, fb, scale=case['scale2'], reduction=fusion,
+                                  frame_range=case['range'], ref_num=case['ref_num'], temperature=case['temperature'],
+                                  sigma1=case['sigma1'], sigma2=case['sigma2'], probability_propagation=prob)
+    g = goldens[f"g7_{strategy}_{'prob_' + fusion if prob else 'label'}_masks"]
+    assert masks.shape == g.shape
+    assert np.mean(masks == g) > 0.9995          # thread-count dependent f32 sums may flip a near-tie pixel
+    assert len(np.unique(g)) >= 3                # the fixture is not degenerate
+
+
+@pytest.mark.parametrize('prob', [False, True])
+def test_three_scale_strategy(goldens, prob):
+    case = gin.STRATEGY_CASE
+    scales, feats = gin.three_scale_features(case)
+    masks = vo.rollout_3_scale(gin.rollout_annotation(case), feats, scales, output_size=case['out3'],
+                               frame_range=case['range'], ref_num=case['ref_num'], temperature=case['temperature'],
+                               sigma1=case['sigma1'], sigma2=case['sigma2'], probability_propagation=prob)
+    g = goldens[f"g7_3-scale_{'prob' if prob else 'label'}_masks"]
+    assert masks.shape == g.shape == (case['T'] - 1,) + tuple(case['out3'])
+    assert np.mean(masks == g) > 0.9995
