@@ -16,6 +16,7 @@
 #include "common.h"
 #include "prop_bf16.h"
 #include "prop_bf16_v5.h"
+#include "prop_bf16_v6.h"
 
 using namespace vosprop;
 
@@ -219,6 +220,13 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream
     static const bool use_v5 = getenv("VOSPROP_V5") != nullptr;
     if (!lp.prob && !lp.lab_lo && use_v5) {
         hipLaunchKernelGGL(prop_bf16_v5_kernel, grid, dim3(kW5 * 64), 0, s, a);
+        return;
+    }
+    // prop_bf16_v6_kernel (4 waves x 64 columns, everything inline asm, softmax of the previous tile under the chains): same
+    // results, same speed as the 8-wave kernel; selectable for experiments (see its header and DESIGN.md 4.5)
+    static const bool use_v6 = getenv("VOSPROP_V6") != nullptr;
+    if (!lp.prob && !lp.lab_lo && use_v6) {
+        hipLaunchKernelGGL(prop_bf16_v6_kernel, grid, dim3(kW6 * 64), 0, s, a);
         return;
     }
     if (lp.prob) {

@@ -4,6 +4,7 @@ features ~ N(0, 0.25^2) rounded to bf16 (logits ~ N(0,1)), uniform one-hot label
 branches are live.  Prints the mean kernel time from HIP events (vosprop_time_last_propagation).
 Used under rocprofv3 for the PMC passes."""
 import argparse
+import os
 import importlib
 import json
 import sys
@@ -62,6 +63,8 @@ def main():
         assert got == n, got
         a = buf.reshape(-1, 8, NS).astype(np.float64) / st['tiles_per_wg']
         names = ['loop', 'ld-issue', 'mfma', 'bar1', 'prefetch', 'max', 'exp', 'labmfma', 'stwrite', 'bar2']
+        if os.environ.get('VOSPROP_V6'):
+            names = ['pre', 'chain0', 'chain1', 'post', 'dmawait', 'barrier']
         print('stamps: cycles per tile')
         for g, sl in (('A (waves 0-3)', slice(0, 4)), ('B (waves 4-7)', slice(4, 8))):
             m = a[:, sl].mean((0, 1))
