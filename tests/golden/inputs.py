@@ -197,6 +197,27 @@ def three_scale_features(case):
     return scales, [strategy_features(case, 10 + i, strategy_map_hw(case, s)) for i, s in enumerate(scales)]
 
 
+# ---- J / boundary-map fixtures (G8) ----
+def metric_masks(seed=501, n=6, H=48, W=64):
+    """(annotation, segmentation, void) boolean stacks: blobs, a shifted copy of them with noise, a void band; frame 4 has an
+    empty annotation, frame 5 is empty in both (union == 0 -> J = 1)."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ann = np.zeros((n, H, W), dtype=bool)
+    seg = np.zeros((n, H, W), dtype=bool)
+    for i in range(n):
+        cy, cx, ry, rx = rs.randint(12, H - 12), rs.randint(16, W - 16), rs.randint(5, 14), rs.randint(6, 18)
+        ann[i] = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        dy, dx = rs.randint(-3, 4), rs.randint(-4, 5)
+        seg[i] = np.roll(np.roll(ann[i], dy, 0), dx, 1) ^ (rs.uniform(size=(H, W)) < 0.01)
+    ann[4] = False
+    ann[5] = False
+    seg[5] = False
+    void = np.zeros((n, H, W), dtype=bool)
+    void[:, :, W // 2 - 2: W // 2 + 2] = True
+    return ann, seg, void
+
+
 def onehot_indices(seed=5, n=40, d=5):
     return np.random.RandomState(seed).randint(0, d, size=n).astype(np.int64)
 

@@ -5,11 +5,12 @@ Run in the build container only (needs /root/reference, which never travels to t
 
     python tests/golden/make_goldens.py
 
-It imports the reference's own `src.model.predict` / `src.utils.inference_utils` with three
+It imports the reference's own `src.model.predict` / `src.utils.inference_utils` / `src.utils.metrics` with four
 in-process shims (nothing installed, nothing fetched):
   * `loguru`  -> stub module with a no-op `logger`      (imported at src/utils/utils.py:9)
   * `np.int`  -> `int`                                   (removed alias used at src/model/predict.py:85)
   * `torchvision.transforms.ColorJitter` -> dummy class  (import chain inference_utils.py:15 -> transforms.py:9,50)
+  * `skimage` -> empty module, import only           (src/utils/metrics.py:6-7; no function that uses it is run)
 and stores ONLY data (inputs' seeds/shapes and the reference's outputs) in `tests/golden/*.npz`.
 Every input is regenerated from `numpy.random.RandomState(seed)` (frozen stream) by
 `tests/golden/inputs.py`, which the tests share with this script.
@@ -211,6 +212,22 @@ def main():
                                   case['sigma2'], case['range'], case['ref_num'], case['temperature'], prob,
                                   case['scale2'], True)
             out[f"g7_3-scale_{'prob' if prob else 'label'}_masks"] = read_masks(td / 'save')
+
+    # ---- G8: eval_j and the boundary map (src/utils/metrics.py:15-45,124-181).  metrics.py imports scikit-image at module
+    # level (absent here); an empty stand-in module lets the import succeed and NOTHING that uses it is run: eval_j and
+    # _seg2bmap do not touch it, f_measure (which does) is not executed - its parity stays unpinned ----
+    sk = types.ModuleType('skimage')
+    skm = types.ModuleType('skimage.morphology')
+    skm.disk = None
+    sk.morphology = skm
+    sys.modules['skimage'] = sk
+    sys.modules['skimage.morphology'] = skm
+    from src.utils import metrics as rmet
+    ann, seg, void = gin.metric_masks()
+    out['g8_j_stack'] = np.asarray(rmet.eval_j(ann, seg), dtype=np.float64)
+    out['g8_j_stack_void'] = np.asarray(rmet.eval_j(ann, seg, void), dtype=np.float64)
+    out['g8_j_single'] = np.asarray([float(rmet.eval_j(ann[i], seg[i])) for i in range(ann.shape[0])], dtype=np.float64)
+    out['g8_bmap'] = np.stack([rmet._seg2bmap(seg[i].copy()) for i in range(seg.shape[0])]).astype(np.uint8)
 
     # ---- index_to_onehot (src/utils/utils.py:59-68) -----------------------------------------
     idx = torch.from_numpy(gin.onehot_indices())
