@@ -111,6 +111,7 @@ def main():
     ap.add_argument('--workload', default='davis480p_r50_dense', choices=sorted(WORKLOADS))
     ap.add_argument('--encoder-dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-encoder-graph', action='store_true', help='run the encoder as eager kernel launches')
     ap.add_argument('--prime', type=int, default=20, help='untimed frames that fill the reference history')
     ap.add_argument('--encoder-batch', type=int, default=16,
                     help='frames encoded per encoder call (features do not depend on the propagated labels)')
@@ -138,6 +139,8 @@ def main():
     net = vos_net.VOSNet(wl['model'])
     model_state = {k: v.clone() for k, v in net.state_dict().items()}
     net.prepare_for_inference(dev, enc_dtype)
+    if not args.no_encoder_graph:
+        net = vos_net.GraphedEncoder(net)     # the batch-16 forward as one HIP graph launch
 
     pool = 32                                    # distinct frames, cycled
     clip, ann = synthetic_clip(H, W, pool, seed=rank, device=dev)

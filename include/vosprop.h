@@ -14,8 +14,8 @@
  *     into its own ring; outputs are written to caller-owned device buffers.
  *   - one ctx per (GPU, stream); a ctx is not thread-safe; there is no global state.
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
- *     no call synchronises the device except vosprop_begin_video (host label upload) and
- *     vosprop_destroy.
+ *     no call synchronises the device except vosprop_begin_video / vosprop_begin_video_labels (use their
+ *     *_on forms to stay stream-ordered) and vosprop_destroy.
  */
 #ifndef VOSPROP_H
 #define VOSPROP_H
@@ -97,6 +97,13 @@ int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H
  * transformed (flips, :130-135): the caller passes the already down-sampled class map (feat_h x feat_w, uint8), the class
  * count d and the size (out_h, out_w) the masks of vosprop_step are up-sampled to. */
 int vosprop_begin_video_labels(vosprop_ctx* ctx, const uint8_t* cls_lowres_host, int d, int out_h, int out_w);
+
+/* Stream-ordered forms of the two calls above: the label upload, the label packing and the state reset are enqueued on `stream`
+ * (the stream the vosprop_step calls of this context use) and the call returns without waiting for the device, so a loop that
+ * walks many videos never drains the GPU at a video boundary.  first_label_host / cls_lowres_host are consumed before return. */
+int vosprop_begin_video_on(vosprop_ctx* ctx, const uint8_t* first_label_host, int H, int W, int* d_out, void* stream);
+int vosprop_begin_video_labels_on(vosprop_ctx* ctx, const uint8_t* cls_lowres_host, int d, int out_h, int out_w,
+                                  void* stream);
 
 /* One iteration of the `inference_single` loop body after the encoder
  * (reference src/utils/inference_utils.py:33-75):

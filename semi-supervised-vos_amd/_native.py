@@ -44,6 +44,8 @@ SYMBOLS = {
     'vosprop_last_error': (ctypes.c_char_p, [_vp]),
     'vosprop_begin_video': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     'vosprop_begin_video_labels': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'vosprop_begin_video_on': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _vp]),
+    'vosprop_begin_video_labels_on': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'vosprop_step': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
     'vosprop_frame_index': (ctypes.c_int, [_vp]),
     'vosprop_predict': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -62,6 +62,9 @@ struct vosprop_ctx {
     size_t part_bytes = 0;
     float* pred_buf = nullptr;     // (kMaxClasses, HW) f32
     uint8_t* cls_tmp = nullptr;    // (HWp)
+    uint8_t* stage_host = nullptr; // pinned (HWp): first labels of a video on their way to the GPU (stream-ordered upload)
+    hipEvent_t stage_ev = nullptr;
+    bool stage_busy = false;
     float* tk_thr = nullptr;       // top-k scratch (allocated when cfg.topk > 0)
     float* tk_m = nullptr;
     unsigned* tk_cnt = nullptr;
@@ -438,6 +441,8 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
     if (!rc) rc = build_coord_table(ctx);
     if (!rc && hipMalloc((void**)&ctx->pred_buf, (size_t)kMaxClasses * ctx->HW * sizeof(float)) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipMalloc((void**)&ctx->cls_tmp, (size_t)ctx->HWp) != hipSuccess) rc = VOSPROP_E_HIP;
+    if (!rc && hipHostMalloc((void**)&ctx->stage_host, (size_t)ctx->HWp, hipHostMallocDefault) != hipSuccess) rc = VOSPROP_E_HIP;
+    if (!rc && hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && cfg->topk > 0) {
         if (hipMalloc((void**)&ctx->tk_thr, (size_t)ctx->HWp * 4) != hipSuccess ||
             hipMalloc((void**)&ctx->tk_m, (size_t)ctx->HWp * 4) != hipSuccess ||
@@ -464,6 +469,8 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     }
     if (ctx->pred_buf) (void)hipFree(ctx->pred_buf);
     if (ctx->cls_tmp) (void)hipFree(ctx->cls_tmp);
+    if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
+    if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
     if (ctx->tk_thr) (void)hipFree(ctx->tk_thr);
     if (ctx->tk_m) (void)hipFree(ctx->tk_m);
     if (ctx->tk_cnt) (void)hipFree(ctx->tk_cnt);
@@ -475,15 +482,19 @@ const char* vosprop_last_error(const vosprop_ctx* ctx) { return ctx ? ctx->err.c
 
 int vosprop_frame_index(const vosprop_ctx* ctx) { return ctx && ctx->in_video ? ctx->frame_idx : -1; }
 
-static int begin_with_lowres(vosprop_ctx* ctx, const std::vector<uint8_t>& cls, int d, int H, int W) {
+// Stream-ordered start of a video: the labels go through a pinned staging buffer owned by the context, everything is enqueued
+// on `s`, nothing waits for the device (the staging buffer is only waited for if the previous upload has not finished).
+static int begin_with_lowres(vosprop_ctx* ctx, const std::vector<uint8_t>& cls, int d, int H, int W, hipStream_t s) {
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipMemcpy(ctx->ring.cls, cls.data(), cls.size(), hipMemcpyHostToDevice));
-    int rc = pack_labels_from_cls(ctx, ctx->ring.cls, ctx->ring.lab_hi, nullptr);
+    if (ctx->stage_busy) HIP_TRY(ctx, hipEventSynchronize(ctx->stage_ev));
+    memcpy(ctx->stage_host, cls.data(), cls.size());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ring.cls, ctx->stage_host, cls.size(), hipMemcpyHostToDevice, s));
+    int rc = pack_labels_from_cls(ctx, ctx->ring.cls, ctx->ring.lab_hi, s);
     if (rc) return rc;
     const size_t lab_slot_b = (size_t)ctx->tiles * 2 * 64 * 8 * sizeof(bf16_t);
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ring.lab_lo, 0, lab_slot_b, nullptr));
-    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ring.lab_lo, 0, lab_slot_b, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->stage_ev, s));
+    ctx->stage_busy = true;
     ctx->in_video = true;
     ctx->frame_idx = 0;
     ctx->d = d;
@@ -492,7 +503,7 @@ static int begin_with_lowres(vosprop_ctx* ctx, const std::vector<uint8_t>& cls, 
     return VOSPROP_OK;
 }
 
-int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H, int W, int* d_out) {
+int vosprop_begin_video_on(vosprop_ctx* ctx, const uint8_t* first_label_host, int H, int W, int* d_out, void* stream) {
     if (!ctx || !first_label_host || H < 1 || W < 1) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
     const int Hd = (int)std::ceil(H * 0.125), Wd = (int)std::ceil(W * 0.125);   // reference predict.py:109-110
     if (Hd != ctx->cfg.feat_h || Wd != ctx->cfg.feat_w)
@@ -506,13 +517,24 @@ int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H
         const int sy = nearest_src(y, H, Hd);
         for (int x = 0; x < Wd; ++x) cls[(size_t)y * Wd + x] = first_label_host[(size_t)sy * W + nearest_src(x, W, Wd)];
     }
-    const int rc = begin_with_lowres(ctx, cls, d, H, W);
+    const int rc = begin_with_lowres(ctx, cls, d, H, W, (hipStream_t)stream);
     if (rc) return rc;
     if (d_out) *d_out = d;
     return VOSPROP_OK;
 }
 
-int vosprop_begin_video_labels(vosprop_ctx* ctx, const uint8_t* cls_lowres_host, int d, int out_h, int out_w) {
+int vosprop_begin_video(vosprop_ctx* ctx, const uint8_t* first_label_host, int H, int W, int* d_out) {
+    if (!ctx) return VOSPROP_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipDeviceSynchronize());   // work of the previous video may be in flight on any stream
+    const int rc = vosprop_begin_video_on(ctx, first_label_host, H, W, d_out, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return VOSPROP_OK;
+}
+
+int vosprop_begin_video_labels_on(vosprop_ctx* ctx, const uint8_t* cls_lowres_host, int d, int out_h, int out_w,
+                                  void* stream) {
     if (!ctx || !cls_lowres_host || out_h < 1 || out_w < 1 || d < 1) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
     if (d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "more than VOSPROP_MAX_CLASSES classes");
     std::vector<uint8_t> cls((size_t)ctx->HWp, 0);
@@ -520,7 +542,17 @@ int vosprop_begin_video_labels(vosprop_ctx* ctx, const uint8_t* cls_lowres_host,
         if (cls_lowres_host[i] >= d) return fail(ctx, VOSPROP_E_INVALID, "class index >= d in the label map");
         cls[(size_t)i] = cls_lowres_host[i];
     }
-    return begin_with_lowres(ctx, cls, d, out_h, out_w);
+    return begin_with_lowres(ctx, cls, d, out_h, out_w, (hipStream_t)stream);
+}
+
+int vosprop_begin_video_labels(vosprop_ctx* ctx, const uint8_t* cls_lowres_host, int d, int out_h, int out_w) {
+    if (!ctx) return VOSPROP_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    const int rc = vosprop_begin_video_labels_on(ctx, cls_lowres_host, d, out_h, out_w, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return VOSPROP_OK;
 }
 
 int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* pred_out_dev, uint8_t* mask_out_dev,

@@ -75,14 +75,19 @@ class PropagationEngine:
             raise VospropError(f'{what} failed ({rc}): {msg.decode() if msg else ""}')
 
     # -- video API --------------------------------------------------------------------------------
-    def begin_video(self, first_label):
-        """first_label: (H, W) integer class map of the first annotation (00000.png).  Returns d."""
+    def begin_video(self, first_label, sync=False):
+        """first_label: (H, W) integer class map of the first annotation (00000.png).  Returns d.  Enqueued on the current
+        stream of the engine's device (vosprop_begin_video_on); sync=True uses the device-synchronising ABI call."""
         lab = np.ascontiguousarray(np.asarray(first_label), dtype=np.uint8)
         if lab.ndim != 2:
             raise ValueError('first_label must be (H, W)')
         d = ctypes.c_int(0)
-        rc = self._L.vosprop_begin_video(self._ctx, lab.ctypes.data_as(ctypes.c_void_p), lab.shape[0], lab.shape[1],
-                                         ctypes.byref(d))
+        if sync:
+            rc = self._L.vosprop_begin_video(self._ctx, lab.ctypes.data_as(ctypes.c_void_p), lab.shape[0], lab.shape[1],
+                                             ctypes.byref(d))
+        else:
+            rc = self._L.vosprop_begin_video_on(self._ctx, lab.ctypes.data_as(ctypes.c_void_p), lab.shape[0], lab.shape[1],
+                                                ctypes.byref(d), _stream_ptr(self.device))
         self._check(rc, 'vosprop_begin_video')
         self.d, self.H, self.W = d.value, lab.shape[0], lab.shape[1]
         return self.d
@@ -93,8 +98,8 @@ class PropagationEngine:
         lab = np.ascontiguousarray(np.asarray(cls_lowres), dtype=np.uint8)
         if lab.shape != (self.feat_h, self.feat_w):
             raise ValueError(f'label map must be ({self.feat_h},{self.feat_w}), got {lab.shape}')
-        rc = self._L.vosprop_begin_video_labels(self._ctx, lab.ctypes.data_as(ctypes.c_void_p), int(d), int(out_hw[0]),
-                                                int(out_hw[1]))
+        rc = self._L.vosprop_begin_video_labels_on(self._ctx, lab.ctypes.data_as(ctypes.c_void_p), int(d), int(out_hw[0]),
+                                                   int(out_hw[1]), _stream_ptr(self.device))
         self._check(rc, 'vosprop_begin_video_labels')
         self.d, self.H, self.W = int(d), int(out_hw[0]), int(out_hw[1])
         return self.d

@@ -14,11 +14,12 @@ import torch.utils.data
 
 from .config import Config
 from .datasets import InferenceDataset, list_videos
+from .io_pipeline import ShmFrameLoader, default_io_workers, make_loader
 from .inference_utils import (inference_2_scale, inference_3_scale, inference_hor_flip, inference_multimodel,
                               inference_single, inference_ver_flip)
 from .sharding import shard_for_rank
 from .utils import load_model
-from .vos_net import VOSNet
+from .vos_net import GraphedEncoder, VOSNet
 
 _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
 
@@ -54,15 +55,21 @@ _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
 @click.option('--encoder-dtype', type=click.Choice(sorted(_DTYPES)), default='bf16',
               help='[engine] encoder precision (the reference runs it under fp16 autocast on GPU).')
 @click.option('--encoder-batch', type=int, default=16, help='[engine] frames per encoder call (look-ahead).')
+@click.option('--io-workers', type=int, default=None,
+              help='[engine] JPEG decode processes (default: min(8, cores - 1); the reference uses 1).')
+@click.option('--png-workers', type=int, default=2, help='[engine] PNG encoder threads.')
+@click.option('--encoder-graph/--no-encoder-graph', default=True,
+              help='[engine] replay the encoder forward of full batches as one captured HIP graph.')
 @click.option('--shard', type=(int, int), default=(0, 1), hidden=True, help='[engine] internal: rank, world')
 def inference_command(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                       inference_strategy, additional_model, additional_model_type, probability, scale, fusion, gpus,
-                      encoder_dtype, encoder_batch, shard):
+                      encoder_dtype, encoder_batch, io_workers, png_workers, encoder_graph, shard):
     if gpus > 1 and shard == (0, 1):
         return _launch_shards(gpus)
     inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_model, additional_model_type, probability, scale, fusion,
-                           encoder_dtype=encoder_dtype, shard=shard, encoder_batch=encoder_batch)
+                           encoder_dtype=encoder_dtype, shard=shard, encoder_batch=encoder_batch, io_workers=io_workers,
+                           png_workers=png_workers, encoder_graph=encoder_graph)
 
 
 def _launch_shards(gpus):
@@ -89,7 +96,8 @@ def _launch_shards(gpus):
 
 def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
-                           reduction, disable=False, encoder_dtype='bf16', shard=(0, 1), encoder_batch=16):
+                           reduction, disable=False, encoder_dtype='bf16', shard=(0, 1), encoder_batch=16, io_workers=None,
+                           png_workers=2, encoder_graph=True):
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)
     if Config.DEVICE.type == 'cuda':
@@ -105,13 +113,26 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
         additional = load_model(VOSNet(model=additional_model_type), additional_resume)
         additional.prepare_for_inference(Config.DEVICE, dtype)
 
+    if Config.DEVICE.type == 'cuda' and encoder_graph:
+        # full batches of one resolution replay a captured HIP graph; everything else (last batch of a video, another
+        # resolution) runs the eager module
+        net = GraphedEncoder(net)
+        if additional is not None:
+            additional = GraphedEncoder(additional)
+
     data_dir = str(Path(data) / 'JPEGImages/480p')
     videos = None
     if shard[1] > 1:
         lengths = {k: len(v) for k, v in list_videos(data_dir).items()}
         videos = shard_for_rank(lengths, shard[0], shard[1])
-    dataset = InferenceDataset(data_dir, disable=disable, inference_strategy=inference_strategy, scale=scale, videos=videos)
-    loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=1)
+    dataset = InferenceDataset(data_dir, disable=disable, inference_strategy=inference_strategy, scale=scale, videos=videos,
+                               raw_uint8=Config.DEVICE.type == 'cuda')
+    n_io = default_io_workers() if io_workers is None else io_workers
+    single_tensor = inference_strategy in ('single', 'multimodel', '3-scale')
+    if Config.DEVICE.type == 'cuda' and single_tensor and n_io > 0 and len(dataset) > 0:
+        loader = ShmFrameLoader(dataset, workers=n_io)       # zero-copy decode ring (io_pipeline.py)
+    else:
+        loader = make_loader(dataset, n_io)
     annotation_dir = Path(data) / 'Annotations/480p'
     if len(dataset) == 0:
         print(json.dumps({'vosprop_stats': {'frames': 0, 'videos': 0, 'seconds': 0.0, 'shard': list(shard)}}))
@@ -121,7 +142,7 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
     with torch.no_grad():
         head = (loader, len(dataset), annotation_dir, last_video, save, sigma_1, sigma_2, frame_range, ref_num,
                 temperature, probability_propagation)
-        opts = dict(encoder_dtype=dtype, stats=stats, encoder_batch=encoder_batch)
+        opts = dict(encoder_dtype=dtype, stats=stats, encoder_batch=encoder_batch, png_workers=png_workers)
         if inference_strategy == 'single':
             inference_single(net, *head, disable, **opts)
         elif inference_strategy == 'hor-flip':
@@ -136,5 +157,7 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
             inference_2_scale(net, *head, scale, reduction, True, disable, **opts)
         elif inference_strategy == '3-scale':
             inference_3_scale(net, *head, scale, disable, **opts)
+    if hasattr(loader, 'close'):
+        loader.close()
     stats['shard'] = list(shard)
     print(json.dumps({'vosprop_stats': stats}))

@@ -68,3 +68,15 @@ def test_inference_cli_matches_oracle(tmp_path):
         assert Image.open(tmp_path / 'out' / vid / '00001.png').mode == 'P'
         assert np.mean(got != want) <= 0.01, f'{vid}: {np.mean(got != want) * 100:.2f} % of pixels differ'
         assert min(vo.mask_iou_per_object(want, got, int(ann.max()) + 1)) >= 0.97
+
+
+def test_device_normalisation_equals_host_normalisation():
+    """uint8 -> f32 ToTensor + Normalize on the GPU (the loader fast path) vs the reference's host transform: IEEE f32 division
+    and subtraction on both sides, so the tensors are identical."""
+    from PIL import Image
+    ds = importlib.import_module('semi-supervised-vos_amd.datasets')
+    rs = np.random.RandomState(0)
+    img = Image.fromarray(rs.randint(0, 256, size=(64, 96, 3)).astype(np.uint8))
+    host = ds.normalize_image(img)
+    dev = ds.normalize_on_device(ds.raw_image(img)[None].cuda())[0].cpu()
+    assert torch.equal(host, dev)

@@ -335,3 +335,105 @@ def test_evaluation_command(tmp_path, vos):
     out = subprocess.run([sys.executable, str(ROOT / 'main.py'), 'evaluation', '-g', str(tmp_path / 'gt'), '-c',
                           str(tmp_path / 'same')], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'j_mean=1.0' in out.stdout, out.stdout + out.stderr
+
+
+def test_async_mask_writer(tmp_path, vos, goldens):
+    """AsyncMaskWriter writes exactly what save_predictions writes (names, mode P, palette, pixels), from tensors or arrays,
+    several videos in flight, and close() re-raises a failed job."""
+    from PIL import Image
+    io = importlib.import_module('semi-supervised-vos_amd.io_pipeline')
+    U = importlib.import_module('semi-supervised-vos_amd.utils')
+    pal = [int(v) for v in goldens['g6_roll_palette']]
+    rs = np.random.RandomState(1)
+    vids = {f'v{i}': rs.randint(0, 4, size=(5, 24, 32)).astype(np.uint8) for i in range(4)}
+    w = io.AsyncMaskWriter(str(tmp_path / 'a'), workers=3)
+    for k, (name, m) in enumerate(vids.items()):
+        w.submit(name, pal, [torch.from_numpy(x) for x in m] if k % 2 else m)
+    assert w.close() == 20
+    for name, m in vids.items():
+        U.save_predictions(m, pal, str(tmp_path / 'b'), name)
+        for i in range(1, 6):
+            a = Image.open(tmp_path / 'a' / name / f'{i:05d}.png')
+            b = Image.open(tmp_path / 'b' / name / f'{i:05d}.png')
+            assert a.mode == b.mode == 'P' and a.getpalette() == b.getpalette()
+            assert np.array_equal(np.asarray(a), np.asarray(b)) and np.array_equal(np.asarray(a), m[i - 1])
+    assert io.AsyncMaskWriter(None).close() == 0
+    bad = io.AsyncMaskWriter(str(tmp_path / 'file_in_the_way'), workers=1)
+    (tmp_path / 'file_in_the_way').write_text('x')
+    bad.submit('v', pal, vids['v0'])
+    with pytest.raises(Exception):
+        bad.close()
+
+
+def test_loader_keeps_the_reference_order_with_many_workers(tmp_path, vos):
+    from PIL import Image
+    io = importlib.import_module('semi-supervised-vos_amd.io_pipeline')
+    ds_mod = importlib.import_module('semi-supervised-vos_amd.datasets')
+    for v in ('b', 'a'):
+        (tmp_path / v).mkdir()
+        for i in range(5):
+            Image.fromarray(np.full((8, 8, 3), 10 * i + (100 if v == 'b' else 0), np.uint8)).save(tmp_path / v / f'{i:05d}.png')
+    ds = ds_mod.InferenceDataset(tmp_path)
+    ref = [(x, (n,)) for x, n in (ds[i] for i in range(len(ds)))]
+    got = list(io.make_loader(ds, io_workers=3, pin=False))
+    assert [n for _, (n,) in got] == ['a'] * 5 + ['b'] * 5
+    for (x, _), (y, _) in zip(ref, got):
+        assert torch.equal(x[None], y)
+    assert 1 <= io.default_io_workers() <= 8
+
+
+def test_raw_uint8_dataset_and_device_normalisation(tmp_path, vos):
+    """The fast path (uint8 frames through the loader, ToTensor + Normalize after the H2D copy) gives the tensors the reference's
+    dataset gives (here on the CPU device: the same torch f32 operations in the same order)."""
+    from PIL import Image
+    ds_mod = importlib.import_module('semi-supervised-vos_amd.datasets')
+    rs = np.random.RandomState(3)
+    (tmp_path / 'v').mkdir()
+    Image.fromarray(rs.randint(0, 256, size=(20, 28, 3)).astype(np.uint8)).save(tmp_path / 'v' / '00000.png')
+    ref, _ = ds_mod.InferenceDataset(tmp_path)[0]
+    raw, _ = ds_mod.InferenceDataset(tmp_path, raw_uint8=True)[0]
+    assert raw.dtype == torch.uint8 and tuple(raw.shape) == (20, 28, 3)
+    assert torch.equal(ds_mod.normalize_on_device(raw[None])[0], ref)
+    (a, b), _ = ds_mod.InferenceDataset(tmp_path, raw_uint8=True, inference_strategy='hor-flip')[0]
+    assert torch.equal(b, a.flip(1))
+
+
+def test_shm_frame_loader(tmp_path, vos):
+    """ShmFrameLoader: in-order, bit-identical frames out of the shared ring with far fewer slots than frames (recycling), an
+    oversized frame through the fallback path, and a decode failure surfaced in the consumer."""
+    from PIL import Image
+    io = importlib.import_module('semi-supervised-vos_amd.io_pipeline')
+    ds_mod = importlib.import_module('semi-supervised-vos_amd.datasets')
+    rs = np.random.RandomState(0)
+    for v, (h, w) in (('a', (16, 24)), ('b', (16, 24)), ('c', (20, 24))):      # video c does not fit a slot
+        (tmp_path / v).mkdir()
+        for i in range(9):
+            Image.fromarray(rs.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(tmp_path / v / f'{i:05d}.png')
+    ds = ds_mod.InferenceDataset(tmp_path, raw_uint8=True)
+    L = io.ShmFrameLoader(ds, workers=3, slots=6, register=False)
+    assert len(L) == 27
+    got, batch = [], []
+    for x, (name,) in L:
+        got.append((x.clone(), name))
+        batch.append(x)
+        if len(batch) == 4:                  # the consumer holds a few frames, then hands them back
+            L.recycle(batch, None)
+            batch = []
+    L.recycle(batch, None)
+    L.close()
+    assert [n for _, n in got] == ['a'] * 9 + ['b'] * 9 + ['c'] * 9
+    for i, (x, _) in enumerate(got):
+        assert x.dtype == torch.uint8 and torch.equal(x[0], ds[i][0])
+
+    class Broken(ds_mod.InferenceDataset):
+        def __getitem__(self, i):
+            if i == 5:
+                raise OSError('truncated file')
+            return super().__getitem__(i)
+    bad = io.ShmFrameLoader(Broken(tmp_path, raw_uint8=True), workers=2, slots=6, register=False)
+    with pytest.raises(RuntimeError, match='truncated file'):
+        for x, _ in bad:
+            bad.recycle([x], None)
+    bad.close()
+    with pytest.raises(ValueError):
+        io.ShmFrameLoader(ds_mod.InferenceDataset(tmp_path), workers=1)
