@@ -56,11 +56,20 @@ struct WorkMap {
     int TT;           // target tiles (kBT pixels each)
     int NT;           // reference steps = n_ref * tiles_per_frame
     int wg_per_xcd;   // I
-    int max_parts;    // partial slots reserved per workgroup
+    int max_parts;    // partial slots reserved per workgroup and phase
+    int phases;       // P: every XCD's part of the reference stream is walked in P consecutive pieces, ALL its workgroups on
+                      // the same piece at the same time, so the piece (|stream| / (8 P) ~ 2 MB at 480p, P = 2) stays in that
+                      // XCD's 4 MB L2.  With P = 1 the workgroups sit at 32 evenly spread offsets of a 4.2 MB cyclic stream:
+                      // reuse distance = the whole stream, 47 % of the L2 requests miss (measured, 500 MB per launch).
 
-    __host__ __device__ inline void xcd_range(int x, int& r0, int& r1) const {
+    __host__ __device__ inline void xcd_range(int x, int& r0, int& r1) const {   // phases == 1 (v5 / v6 kernels)
         r0 = (int)((long long)x * NT / kXcd);
         r1 = (int)((long long)(x + 1) * NT / kXcd);
+    }
+    __host__ __device__ inline void part_range(int x, int ph, int& r0, int& r1) const {
+        const long long k = (long long)x * phases + ph, n = (long long)kXcd * phases;
+        r0 = (int)(k * NT / n);
+        r1 = (int)((k + 1) * NT / n);
     }
     // [q0, q1) of workgroup i in XCD x, in units of steps of the flattened (tt, step) space
     __host__ __device__ inline void wg_range(int rx, int i, long long& q0, long long& q1) const {

@@ -162,23 +162,36 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
     long long I = per_xcd / 4;   // at least ~4 tile steps per workgroup
     p.map.wg_per_xcd = (int)(I < 1 ? 1 : (I > 32 ? 32 : I));
     p.map.max_parts = 1;
+    // phases: keep each piece of an XCD's sub-stream (features + labels, ~18.4 KB per tile) within about half of its 4 MB L2
+    static const char* ph_env = getenv("VOSPROP_PHASES");
+    static const bool single_phase_kernels = getenv("VOSPROP_V5") != nullptr || getenv("VOSPROP_V6") != nullptr;
+    int P = 1;
+    if (ph_env) P = atoi(ph_env);
+    else {
+        const double sub_mb = (double)NT / kXcd * 18.4e3 / 1e6;
+        while (P < 8 && sub_mb / P > 2.2) ++P;
+    }
+    if (P < 1 || single_phase_kernels || p.map.wg_per_xcd < 32) P = 1;
+    p.map.phases = P;
     std::vector<std::vector<int>> lists((size_t)ctx->TT);
     for (int pass = 0; pass < 2; ++pass) {
         for (int x = 0; x < kXcd; ++x) {
-            int r0, r1;
-            p.map.xcd_range(x, r0, r1);
-            const int RX = r1 - r0;
-            if (RX <= 0) continue;
-            for (int i = 0; i < p.map.wg_per_xcd; ++i) {
-                long long q0, q1;
-                p.map.wg_range(RX, i, q0, q1);
-                if (q1 <= q0) continue;
-                const int tf = (int)(q0 / RX), tl = (int)((q1 - 1) / RX);
-                if (pass == 0) {
-                    if (tl - tf + 1 > p.map.max_parts) p.map.max_parts = tl - tf + 1;
-                } else {
-                    const int b = i * kXcd + x;
-                    for (int tt = tf; tt <= tl; ++tt) lists[(size_t)tt].push_back(b * p.map.max_parts + (tt - tf));
+            for (int ph = 0; ph < P; ++ph) {
+                int r0, r1;
+                p.map.part_range(x, ph, r0, r1);
+                const int RX = r1 - r0;
+                if (RX <= 0) continue;
+                for (int i = 0; i < p.map.wg_per_xcd; ++i) {
+                    long long q0, q1;
+                    p.map.wg_range(RX, i, q0, q1);
+                    if (q1 <= q0) continue;
+                    const int tf = (int)(q0 / RX), tl = (int)((q1 - 1) / RX);
+                    if (pass == 0) {
+                        if (tl - tf + 1 > p.map.max_parts) p.map.max_parts = tl - tf + 1;
+                    } else {
+                        const int b = (i * kXcd + x) * P + ph;
+                        for (int tt = tf; tt <= tl; ++tt) lists[(size_t)tt].push_back(b * p.map.max_parts + (tt - tf));
+                    }
                 }
             }
         }
@@ -188,7 +201,7 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
         off[(size_t)tt + 1] = off[(size_t)tt] + (int)lists[(size_t)tt].size();
         flat.insert(flat.end(), lists[(size_t)tt].begin(), lists[(size_t)tt].end());
     }
-    p.n_parts = kXcd * p.map.wg_per_xcd * p.map.max_parts;
+    p.n_parts = kXcd * p.map.wg_per_xcd * p.map.max_parts * P;
     HIP_TRY(ctx, hipMalloc((void**)&p.d_off, off.size() * sizeof(int)));
     HIP_TRY(ctx, hipMalloc((void**)&p.d_list, (flat.size() + 1) * sizeof(int)));
     HIP_TRY(ctx, hipMemcpy(p.d_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));

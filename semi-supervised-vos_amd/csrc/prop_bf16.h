@@ -368,13 +368,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
 
     // ---- this workgroup's share of the (target tile, reference step) space ----
     const int x = blockIdx.x & (kXcd - 1), wi = blockIdx.x >> 3;
+    for (int ph = 0; ph < A.map.phases; ++ph) {   // (body not re-indented) one piece of this XCD's part of the reference stream
     int rx0, rx1;
-    A.map.xcd_range(x, rx0, rx1);
+    A.map.part_range(x, ph, rx0, rx1);
     const int RX = rx1 - rx0;
-    if (RX <= 0) return;
+    if (RX <= 0) continue;
     long long q0, q1;
     A.map.wg_range(RX, wi, q0, q1);
-    if (q1 <= q0) return;
+    if (q1 <= q0) continue;
     const int tt_first = (int)(q0 / RX);
     const int TPF = A.tiles_per_frame;
     const float c = A.c;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
 
         // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns (dense); (m, 2 x kTopkMax group maxima)
         // in top-k pass 1; (m, l) in top-k pass 2 ----
-        float* part = A.part + (((size_t)blockIdx.x * A.map.max_parts + (tt - tt_first)) * A.part_rows) * kBT
+        float* part = A.part + ((((size_t)blockIdx.x * A.map.phases + ph) * A.map.max_parts + (tt - tt_first)) * A.part_rows) * kBT
                       + wave * kColsPerWave + j;
         if (MODE == 1) {
             const float mm = half_max(st.m);
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             }
         }
     }
+    }   // phases
 }
 
 }  // namespace vosprop
