@@ -216,6 +216,17 @@ def main():
     torch.cuda.synchronize()
     prop_fps = 50 / (time.perf_counter() - t1)
 
+    # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them, in
+    # their own passes), so the line carries the committed measurement for this workload (tools/traffic_pmc.sh) or null
+    traffic, traffic_src = None, None
+    tj = Path(__file__).resolve().parent / 'profiles' / 'r01_prop_kernel_traffic.json'
+    if args.workload == 'davis480p_r50_dense' and tj.exists():
+        try:
+            t = json.loads(tj.read_text())
+            traffic = float(t['traffic_bytes_per_launch'])
+            traffic_src = 'profiles/r01_prop_kernel_traffic.json: ' + t['how']
+        except Exception:
+            traffic = None
     if rank == 0:
         out = {
             'metric': '480p frames/sec at 1/2/4/8 MI355X; mask IoU delta vs CPU ref',
@@ -229,7 +240,7 @@ def main():
             'propagation_only_frames_per_s_per_gpu': prop_fps,
             'roofline': {'kernel': 'prop_bf16_kernel', 'bound': 'mfma', 'achieved': achieved,
                          'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
-                         'traffic': None, 'kernel_us': prop_us, 'flops_per_launch': st['flops'],
+                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us, 'flops_per_launch': st['flops'],
                          'algorithmic_bytes_per_launch': st['bytes'], 'workgroups': st['workgroups']},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -46,37 +46,19 @@ __host__ __device__ inline void split3(float x, float& h, float& m, float& l) {
     l = bf16_round(x - h - m);
 }
 
-// Work decomposition of one propagation ("stream-K" over reference tiles, XCD-partitioned):
-//   the N*tiles_per_frame reference steps are cut into kXcd contiguous parts; the workgroups with
-//   blockIdx % 8 == x walk part x for every target tile, so that part's features stay in that XCD's L2.
-//   Inside an XCD the (target tile, step) space of TT * |part| steps is cut evenly over `wg_per_xcd`
-//   workgroups, target-major, so a workgroup streams a contiguous run of reference tiles against one
-//   (rarely two or three) target tiles.  Both the kernel and combine_kernel evaluate this map.
-struct WorkMap {
-    int TT;           // target tiles (kBT pixels each)
-    int NT;           // reference steps = n_ref * tiles_per_frame
-    int wg_per_xcd;   // I
-    int max_parts;    // partial slots reserved per workgroup and phase
-    int phases;       // P: every XCD's part of the reference stream is walked in P consecutive pieces, ALL its workgroups on
-                      // the same piece at the same time, so the piece (|stream| / (8 P) ~ 2 MB at 480p, P = 2) stays in that
-                      // XCD's 4 MB L2.  With P = 1 the workgroups sit at 32 evenly spread offsets of a 4.2 MB cyclic stream:
-                      // reuse distance = the whole stream, 47 % of the L2 requests miss (measured, 500 MB per launch).
-
-    __host__ __device__ inline void xcd_range(int x, int& r0, int& r1) const {   // phases == 1 (v5 / v6 kernels)
-        r0 = (int)((long long)x * NT / kXcd);
-        r1 = (int)((long long)(x + 1) * NT / kXcd);
-    }
-    __host__ __device__ inline void part_range(int x, int ph, int& r0, int& r1) const {
-        const long long k = (long long)x * phases + ph, n = (long long)kXcd * phases;
-        r0 = (int)(k * NT / n);
-        r1 = (int)((k + 1) * NT / n);
-    }
-    // [q0, q1) of workgroup i in XCD x, in units of steps of the flattened (tt, step) space
-    __host__ __device__ inline void wg_range(int rx, int i, long long& q0, long long& q1) const {
-        const long long Q = (long long)TT * rx;
-        q0 = Q * i / wg_per_xcd;
-        q1 = Q * (i + 1) / wg_per_xcd;
-    }
+// Work decomposition of one propagation.  The (target tile, reference tile) space is cut into SEGMENTS - a run of
+// consecutive reference tiles against one target tile - and every workgroup walks a short list of them (built on the host,
+// engine.hip get_plan; the kernels only read their list).  The reference stream is cut into kXcd contiguous parts and the
+// workgroups with blockIdx % 8 == x (they run on XCD x: tools/xcc_probe.hip) only touch part x, so each L2 sees 1/8 of the
+// features.  Inside an XCD the workgroups walk their part IN LOCKSTEP (same reference tiles at the same time, each against
+// its own target tile) so a tile is fetched from HBM once and then hit in L2 by the other workgroups; the target tiles left
+// over when their number is not a multiple of the workgroup count are split between "primary" workgroups (head of the part)
+// and "extra" ones (the tail of the part, a sub-megabyte region that stays in L2 as well).
+struct Segment {
+    int tt;        // target tile (kBT pixels)
+    int r_lo;      // first reference tile (index into the sampled stream: frame n = r / tiles_per_frame)
+    int n_steps;   // reference tiles in the run
+    int slot;      // partial slot written by this segment: part[slot][part_rows][kBT]
 };
 
 // Per-launch description of one propagation (passed by value as a kernel argument).
@@ -85,10 +67,11 @@ struct PropArgs {
     const bf16_t* coord_tab;    // [HWp/32][2][32][8]    reference-side spatial channels
     const bf16_t* lab_hi;       // [cap][HWp/32][2][64][8] labels in MFMA A-operand order (hi part)
     const bf16_t* lab_lo;       // same, low part (probability mode) or nullptr
-    float* part;                // [8*I][max_parts][2+d][kBT]  per-workgroup partial (m, l, numerators)
+    float* part;                // [n_segments][part_rows][kBT]  per-segment partial (m, l, numerators)
     int slot[kMaxRef];          // ring slot of each sampled reference frame
     unsigned long long sparse_mask;   // bit n set: frame n uses sigma2 (the "interval" frames)
-    WorkMap map;
+    const Segment* segs;        // segment table of this launch
+    const int* seg_off;         // [grid + 1] segments of workgroup b: segs[seg_off[b]] .. segs[seg_off[b + 1] - 1]
     int target_slot;
     int n_ref;
     int HW, HWp, Wd;

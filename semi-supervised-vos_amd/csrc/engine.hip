@@ -44,10 +44,14 @@ struct LastProp {
 // Device copy of the partial-slot lists of one work decomposition (depends only on TT, NT).
 struct Plan {
     int NT = -1;
-    WorkMap map;
-    int n_parts = 0;          // total partial slots = grid * max_parts
+    int grid = 0;             // workgroups = 8 * wg_per_xcd
+    int wg_per_xcd = 0;
+    int steps_per_wg = 0;     // reference tiles the busiest workgroup walks (stats)
+    int n_parts = 0;          // total partial slots = number of segments
     int* d_off = nullptr;     // [TT + 1]
     int* d_list = nullptr;    // slot indices, CSR by target tile
+    Segment* d_segs = nullptr;
+    int* d_seg_off = nullptr; // [grid + 1]
 };
 
 }  // namespace
@@ -151,61 +155,113 @@ int ensure_part(vosprop_ctx* ctx, size_t bytes) {
 
 // Work decomposition for NT reference steps (see WorkMap in common.h) + the CSR list, per target tile, of the
 // partial slots that will hold it.  Cached per NT; built on first use (a few microseconds of host work).
+// Pure host function: the segment lists of every workgroup (index b = i * 8 + x runs on XCD x) for TT target tiles and NT
+// reference tiles.  Returns the workgroups per XCD.
+int build_segments(int TT, int NT, bool streamk, std::vector<std::vector<Segment>>& per_wg) {
+    long long per_xcd = ((long long)TT * NT + kXcd - 1) / kXcd;
+    long long Iq = per_xcd / 4;   // at least ~4 tile steps per workgroup
+    const int I = (int)(Iq < 1 ? 1 : (Iq > 32 ? 32 : Iq));
+    per_wg.assign((size_t)(kXcd * I), {});
+    auto add = [&](int x, int i, int tt, int r_lo, int n) {
+        if (n > 0) per_wg[(size_t)(i * kXcd + x)].push_back(Segment{tt, r_lo, n, 0});
+    };
+    for (int x = 0; x < kXcd; ++x) {
+        const int r0 = (int)((long long)x * NT / kXcd), r1 = (int)((long long)(x + 1) * NT / kXcd);
+        const int RX = r1 - r0;
+        if (RX <= 0) continue;
+        if (streamk) {
+            const long long Q = (long long)TT * RX;
+            for (int i = 0; i < I; ++i) {
+                long long q = Q * i / I;
+                const long long q1 = Q * (i + 1) / I;
+                while (q < q1) {
+                    const int tt = (int)(q / RX);
+                    long long qe = (long long)(tt + 1) * RX;
+                    if (qe > q1) qe = q1;
+                    add(x, i, tt, r0 + (int)(q - (long long)tt * RX), (int)(qe - q));
+                    q = qe;
+                }
+            }
+            continue;
+        }
+        // lockstep map: k full rounds (workgroup i takes target tile j*I + i over the whole part), then the leftover tiles
+        const int k = TT / I, rem = TT - k * I;
+        for (int j = 0; j < k; ++j)
+            for (int i = 0; i < I; ++i) add(x, i, j * I + i, r0, RX);
+        if (rem > 0) {
+            const int E = I - rem;                                        // extra workgroups (>= 1)
+            // head length U: the primaries walk U tiles in one segment, the E extras share rem * (RX - U) tail tiles in
+            // several short segments; a segment start (target fragments, staging prologue, partial write) costs about as
+            // much as `seg_cost` tile steps, so U is chosen to equalise  U + c  and  tail share + c * segments
+            static const char* sc_env = getenv("VOSPROP_SEGCOST");
+            const double seg_cost = sc_env ? atof(sc_env) : 3.0;
+            int U = RX;
+            double best = 1e30;
+            for (int u = 1; u <= RX; ++u) {
+                const int tl = RX - u;
+                const double share = (double)rem * tl / E;
+                const double nseg = tl > 0 ? share / tl + 1.0 : 0.0;
+                const double cost = std::max(u + seg_cost, share + seg_cost * nseg);
+                if (cost < best) { best = cost; U = u; }
+            }
+            for (int i = 0; i < rem; ++i) add(x, i, k * I + i, r0, U);   // primaries: head of their own tile, in lockstep
+            const int tail = RX - U;                                      // per leftover tile, walked by the extras
+            const long long Q = (long long)rem * tail;
+            for (int e = 0; e < E && tail > 0; ++e) {
+                long long q = Q * e / E;
+                const long long q1 = Q * (e + 1) / E;
+                while (q < q1) {
+                    const int t = (int)(q / tail);
+                    long long qe = (long long)(t + 1) * tail;
+                    if (qe > q1) qe = q1;
+                    add(x, rem + e, k * I + t, r0 + U + (int)(q - (long long)t * tail), (int)(qe - q));
+                    q = qe;
+                }
+            }
+        }
+    }
+    return I;
+}
+
 int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
     for (const Plan& p : ctx->plans)
         if (p.NT == NT) { *out = &p; return VOSPROP_OK; }
     Plan p;
     p.NT = NT;
-    p.map.TT = ctx->TT;
-    p.map.NT = NT;
-    long long per_xcd = ((long long)ctx->TT * NT + kXcd - 1) / kXcd;
-    long long I = per_xcd / 4;   // at least ~4 tile steps per workgroup
-    p.map.wg_per_xcd = (int)(I < 1 ? 1 : (I > 32 ? 32 : I));
-    p.map.max_parts = 1;
-    // phases: keep each piece of an XCD's sub-stream (features + labels, ~18.4 KB per tile) within about half of its 4 MB L2
-    static const char* ph_env = getenv("VOSPROP_PHASES");
-    static const bool single_phase_kernels = getenv("VOSPROP_V5") != nullptr || getenv("VOSPROP_V6") != nullptr;
-    int P = 1;
-    if (ph_env) P = atoi(ph_env);
-    else {
-        const double sub_mb = (double)NT / kXcd * 18.4e3 / 1e6;
-        while (P < 8 && sub_mb / P > 2.2) ++P;
-    }
-    if (P < 1 || single_phase_kernels || p.map.wg_per_xcd < 32) P = 1;
-    p.map.phases = P;
-    std::vector<std::vector<int>> lists((size_t)ctx->TT);
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int x = 0; x < kXcd; ++x) {
-            for (int ph = 0; ph < P; ++ph) {
-                int r0, r1;
-                p.map.part_range(x, ph, r0, r1);
-                const int RX = r1 - r0;
-                if (RX <= 0) continue;
-                for (int i = 0; i < p.map.wg_per_xcd; ++i) {
-                    long long q0, q1;
-                    p.map.wg_range(RX, i, q0, q1);
-                    if (q1 <= q0) continue;
-                    const int tf = (int)(q0 / RX), tl = (int)((q1 - 1) / RX);
-                    if (pass == 0) {
-                        if (tl - tf + 1 > p.map.max_parts) p.map.max_parts = tl - tf + 1;
-                    } else {
-                        const int b = (i * kXcd + x) * P + ph;
-                        for (int tt = tf; tt <= tl; ++tt) lists[(size_t)tt].push_back(b * p.map.max_parts + (tt - tf));
-                    }
-                }
-            }
+    const int TT = ctx->TT;
+    static const char* map_env = getenv("VOSPROP_MAP");   // "streamk": the round-1 map (contiguous shares, experiments only)
+    const bool streamk = map_env && std::string(map_env) == "streamk";
+    std::vector<std::vector<Segment>> per_wg;
+    p.wg_per_xcd = build_segments(TT, NT, streamk, per_wg);
+    p.grid = kXcd * p.wg_per_xcd;
+    std::vector<Segment> segs;
+    std::vector<int> seg_off((size_t)p.grid + 1, 0);
+    std::vector<std::vector<int>> lists((size_t)TT);
+    for (int b = 0; b < p.grid; ++b) {
+        int steps = 0;
+        for (Segment sg : per_wg[(size_t)b]) {
+            sg.slot = (int)segs.size();
+            lists[(size_t)sg.tt].push_back(sg.slot);
+            segs.push_back(sg);
+            steps += sg.n_steps;
         }
+        if (steps > p.steps_per_wg) p.steps_per_wg = steps;
+        seg_off[(size_t)b + 1] = (int)segs.size();
     }
-    std::vector<int> off((size_t)ctx->TT + 1, 0), flat;
-    for (int tt = 0; tt < ctx->TT; ++tt) {
+    p.n_parts = (int)segs.size();
+    std::vector<int> off((size_t)TT + 1, 0), flat;
+    for (int tt = 0; tt < TT; ++tt) {
         off[(size_t)tt + 1] = off[(size_t)tt] + (int)lists[(size_t)tt].size();
         flat.insert(flat.end(), lists[(size_t)tt].begin(), lists[(size_t)tt].end());
     }
-    p.n_parts = kXcd * p.map.wg_per_xcd * p.map.max_parts * P;
     HIP_TRY(ctx, hipMalloc((void**)&p.d_off, off.size() * sizeof(int)));
     HIP_TRY(ctx, hipMalloc((void**)&p.d_list, (flat.size() + 1) * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc((void**)&p.d_segs, (segs.size() + 1) * sizeof(Segment)));
+    HIP_TRY(ctx, hipMalloc((void**)&p.d_seg_off, seg_off.size() * sizeof(int)));
     HIP_TRY(ctx, hipMemcpy(p.d_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(p.d_list, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(p.d_segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(p.d_seg_off, seg_off.data(), seg_off.size() * sizeof(int), hipMemcpyHostToDevice));
     ctx->plans.push_back(p);
     *out = &ctx->plans.back();
     return VOSPROP_OK;
@@ -296,13 +352,14 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     const Plan* plan = nullptr;
     int rc = get_plan(ctx, n_ref * ctx->tiles, &plan);
     if (rc) return rc;
-    a.map = plan->map;
+    a.segs = plan->d_segs;
+    a.seg_off = plan->d_seg_off;
     a.c = (float)((double)temperature * 1.4426950408889634);
     a.g1 = 1.0 / ((double)sigma1 * sigma1 * temperature);
     a.g2 = 1.0 / ((double)sigma2 * sigma2 * temperature);
     a.two_over_w = 2.0 / ctx->cfg.feat_w;
     a.gamma = 1.0 + 1.0 / ((double)ctx->cfg.feat_w * ctx->cfg.feat_w);
-    lp.grid = kXcd * plan->map.wg_per_xcd;
+    lp.grid = plan->grid;
     lp.prob = prob;
     lp.lab_lo = topk ? false : lab_lo;
     lp.topk = topk;
@@ -401,6 +458,21 @@ void vosprop_default_config(vosprop_config* cfg, int feat_h, int feat_w) {
     cfg->ring_capacity = 0;
 }
 
+/* test hook (no GPU needed): segment table for TT target tiles x NT reference tiles; rows of out = (workgroup, tt, r_lo, n_steps) */
+int vosprop_debug_plan(int TT, int NT, int streamk, int* out, int cap_rows) {
+    std::vector<std::vector<Segment>> per_wg;
+    build_segments(TT, NT, streamk != 0, per_wg);
+    int n = 0;
+    for (size_t b = 0; b < per_wg.size(); ++b)
+        for (const Segment& sg : per_wg[b]) {
+            if (out && n < cap_rows) {
+                out[4 * n] = (int)b; out[4 * n + 1] = sg.tt; out[4 * n + 2] = sg.r_lo; out[4 * n + 3] = sg.n_steps;
+            }
+            ++n;
+        }
+    return n;
+}
+
 int vosprop_sample_frames(int frame_idx, int frame_range, int num_refs, int* out) {
     // reference src/model/predict.py:74-89; float64 linspace + truncation, as numpy does it
     int n = 0;
@@ -479,6 +551,8 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     for (Plan& p : ctx->plans) {
         if (p.d_off) (void)hipFree(p.d_off);
         if (p.d_list) (void)hipFree(p.d_list);
+        if (p.d_segs) (void)hipFree(p.d_segs);
+        if (p.d_seg_off) (void)hipFree(p.d_seg_off);
     }
     if (ctx->pred_buf) (void)hipFree(ctx->pred_buf);
     if (ctx->cls_tmp) (void)hipFree(ctx->cls_tmp);

@@ -366,17 +366,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
     const int j = lane & 31;       // MFMA row (A operand) / column (B operand, C/D)
     const int h = lane >> 5;       // k-half of the operand fragments / row-half of the accumulator
 
-    // ---- this workgroup's share of the (target tile, reference step) space ----
-    const int x = blockIdx.x & (kXcd - 1), wi = blockIdx.x >> 3;
-    for (int ph = 0; ph < A.map.phases; ++ph) {   // (body not re-indented) one piece of this XCD's part of the reference stream
-    int rx0, rx1;
-    A.map.part_range(x, ph, rx0, rx1);
-    const int RX = rx1 - rx0;
-    if (RX <= 0) continue;
-    long long q0, q1;
-    A.map.wg_range(RX, wi, q0, q1);
-    if (q1 <= q0) continue;
-    const int tt_first = (int)(q0 / RX);
     const int TPF = A.tiles_per_frame;
     const float c = A.c;
     const bool ragged = A.HW != A.HWp;
@@ -395,15 +384,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
         return (unsigned)(row * 512 + ch * 16);
     };
     const unsigned src_a = feat_src_off(wave), src_b = feat_src_off(wave + 8), src_c = feat_src_off(16);
-    long long q = q0;
-    while (q < q1) {
-        // ---- one segment: a run of reference steps against ONE target tile ----
-        const int tt = (int)(q / RX);
-        const int r_lo = rx0 + (int)(q - (long long)tt * RX);
-        long long q_end = (long long)(tt + 1) * RX;
-        if (q_end > q1) q_end = q1;
-        const int n_steps = (int)(q_end - q);
-        q = q_end;
+    // ---- this workgroup's segments (common.h): runs of reference tiles, each against ONE target tile ----
+    const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
+    for (int si = seg0; si < seg1; ++si) {
+        const Segment sg = A.segs[si];
+        const int tt = __builtin_amdgcn_readfirstlane(sg.tt);
+        const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);
+        const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
+        const int part_slot = __builtin_amdgcn_readfirstlane(sg.slot);
 
         // target (B operand) fragments: 32 columns x 256 channels per wave, resident in registers
         const int t = tt * kBT + wave * kColsPerWave + j;
@@ -592,8 +580,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
 
         // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns (dense); (m, 2 x kTopkMax group maxima)
         // in top-k pass 1; (m, l) in top-k pass 2 ----
-        float* part = A.part + ((((size_t)blockIdx.x * A.map.phases + ph) * A.map.max_parts + (tt - tt_first)) * A.part_rows) * kBT
-                      + wave * kColsPerWave + j;
+        float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + j;
         if (MODE == 1) {
             const float mm = half_max(st.m);
             if (h == 0) part[0] = mm;
@@ -614,7 +601,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             }
         }
     }
-    }   // phases
 }
 
 }  // namespace vosprop

@@ -163,15 +163,6 @@ __global__ __launch_bounds__(kW6 * 64, 1) void prop_bf16_v6_kernel(const PropArg
     const int j = lane & 31;
     const int h = lane >> 5;
 
-    const int x = blockIdx.x & (kXcd - 1), wi = blockIdx.x >> 3;
-    int rx0, rx1;
-    A.map.xcd_range(x, rx0, rx1);
-    const int RX = rx1 - rx0;
-    if (RX <= 0) return;
-    long long q0, q1;
-    A.map.wg_range(RX, wi, q0, q1);
-    if (q1 <= q0) return;
-    const int tt_first = (int)(q0 / RX);
     const int TPF = A.tiles_per_frame;
     const float c = A.c;
     f32x2 c2;
@@ -193,14 +184,13 @@ __global__ __launch_bounds__(kW6 * 64, 1) void prop_bf16_v6_kernel(const PropArg
 #pragma unroll
     for (int i = 0; i < 5; ++i) src_off[i] = feat_src_off(wave + 4 * i < 17 ? wave + 4 * i : 0);
 
-    long long q = q0;
-    while (q < q1) {
-        const int tt = (int)(q / RX);
-        const int r_lo = rx0 + (int)(q - (long long)tt * RX);
-        long long q_end = (long long)(tt + 1) * RX;
-        if (q_end > q1) q_end = q1;
-        const int n_steps = (int)(q_end - q);
-        q = q_end;
+    const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
+    for (int si = seg0; si < seg1; ++si) {   // this workgroup's segments (common.h)
+        const Segment sg = A.segs[si];
+        const int tt = __builtin_amdgcn_readfirstlane(sg.tt);
+        const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);
+        const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
+        const int part_slot = __builtin_amdgcn_readfirstlane(sg.slot);
 
         // ---- target fragments -> AGPRs (straight from HBM), target-side spatial channels -> VGPRs ----
         bf16x8 Bt[2][16];
@@ -552,7 +542,7 @@ __global__ __launch_bounds__(kW6 * 64, 1) void prop_bf16_v6_kernel(const PropArg
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const float lsum = half_sum(st_l[cb]);
-            float* part = A.part + (((size_t)blockIdx.x * A.map.max_parts + (tt - tt_first)) * A.part_rows) * kBT
+            float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT
                           + wave * 64 + cb * 32 + j;
             if (h == 0) {
                 part[0] = st_m[cb];

@@ -1,4 +1,5 @@
 """Host-side logic and the C-ABI surface, on CPU (no GPU, no compute calls through the ABI)."""
+import collections
 import ctypes
 import importlib
 import json
@@ -437,3 +438,39 @@ def test_shm_frame_loader(tmp_path, vos):
     bad.close()
     with pytest.raises(ValueError):
         io.ShmFrameLoader(ds_mod.InferenceDataset(tmp_path), workers=1)
+
+
+@pytest.mark.parametrize('TT,NT', [(26, 1809), (26, 201), (7, 57), (57, 4050), (1, 8), (1, 1), (33, 999), (64, 640)])
+@pytest.mark.parametrize('streamk', [0, 1])
+def test_work_plan_covers_every_unit_once(vos, TT, NT, streamk):
+    """The segment table the kernels walk (engine.hip build_segments, through the vosprop_debug_plan test hook): every
+    (target tile, reference tile) unit exactly once, a workgroup only touches its own XCD's eighth of the reference stream,
+    loads are balanced, and the lockstep map keeps the workgroups of an XCD on the same reference tiles."""
+    L = vos._native.lib()
+    L.vosprop_debug_plan.restype = ctypes.c_int
+    L.vosprop_debug_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    n = L.vosprop_debug_plan(TT, NT, streamk, None, 0)
+    buf = (ctypes.c_int * (4 * n))()
+    assert L.vosprop_debug_plan(TT, NT, streamk, buf, n) == n
+    rows = np.ctypeslib.as_array(buf).reshape(n, 4)
+    cover = np.zeros((TT, NT), np.int32)
+    load = collections.Counter()
+    for b, tt, r_lo, ns in rows:
+        x = b % 8
+        assert ns > 0 and x * NT // 8 <= r_lo and r_lo + ns <= (x + 1) * NT // 8
+        cover[tt, r_lo:r_lo + ns] += 1
+        load[b] += ns + (0 if streamk else 3)       # the lockstep map prices a segment start at 3 tile steps (VOSPROP_SEGCOST)
+    assert cover.min() == 1 and cover.max() == 1
+    if TT * NT >= 8 * 32 * 8:
+        per_xcd = collections.defaultdict(list)
+        for b, v in load.items():
+            per_xcd[b % 8].append(v)
+        for x, v in per_xcd.items():
+            assert max(v) <= min(v) * 1.1 + 8, (x, sorted(v))
+    if not streamk and TT >= 32:
+        # first round of the lockstep map: the 32 workgroups of XCD 0 start at the same reference tile with the same length
+        first = {}
+        for b, tt, r_lo, ns in rows:
+            if b % 8 == 0 and b not in first:
+                first[b] = (r_lo, ns)
+        assert len(set(first.values())) == 1
