@@ -136,6 +136,13 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
                     float temperature, float sigma1, float sigma2, int probability, float* out_dev,
                     void* stream);
 
+/* Encoder epilogue, context-free: y = act(y + bias[c] (+ residual)) in place over a channels-last tensor viewed as
+ * (pixels, channels); replaces the bias / BatchNorm shift, the `out += identity` and the ReLU that follow every convolution of the
+ * reference's residual units (src/model/backbone/resnet.py:45-58, 81-95) by one pass.  channels % 8 == 0; y, bias, residual share
+ * `dtype` (VOSPROP_DT_*); residual may be NULL; relu != 0 applies max(., 0).  Device pointers, enqueued on `stream`. */
+int vosprop_bias_act(void* y, const void* bias, const void* residual, long long pixels, int channels, int relu, int dtype,
+                     void* stream);
+
 /* Frame sampler, reference `sample_frames` (src/model/predict.py:74-89).  Host-side, exact.
  * out must hold num_refs ints (or frame_idx when frame_idx <= num_refs); returns the count. */
 int vosprop_sample_frames(int frame_idx, int frame_range, int num_refs, int* out);

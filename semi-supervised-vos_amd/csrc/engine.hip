@@ -17,6 +17,7 @@
 #include "prop_bf16.h"
 #include "prop_bf16_v5.h"
 #include "prop_bf16_v6.h"
+#include "encoder_ops.h"
 
 using namespace vosprop;
 
@@ -456,6 +457,37 @@ void vosprop_default_config(vosprop_config* cfg, int feat_h, int feat_w) {
     cfg->topk = 0;
     cfg->precision = VOSPROP_PREC_BF16;
     cfg->ring_capacity = 0;
+}
+
+int vosprop_bias_act(void* y, const void* bias, const void* residual, long long pixels, int channels, int relu, int dtype,
+                     void* stream) {
+    if (!y || !bias || pixels < 0 || channels < 8 || channels % 8) return VOSPROP_E_INVALID;
+    if (pixels == 0) return VOSPROP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = pixels * channels;
+    const long long groups = dtype == VOSPROP_DT_F32 ? n / 4 : n / 8;
+    long long blocks = (groups + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride: 16 workgroups per CU
+    const dim3 grid((unsigned)blocks), block(256);
+#define VOSPROP_BA(KER, T)                                                                                                  \
+    do {                                                                                                                    \
+        if (relu && residual) hipLaunchKernelGGL((KER<T, true, true>), grid, block, 0, s, (T*)y, (const T*)bias, (const T*)residual, groups, channels);   \
+        else if (relu) hipLaunchKernelGGL((KER<T, true, false>), grid, block, 0, s, (T*)y, (const T*)bias, (const T*)nullptr, groups, channels);          \
+        else if (residual) hipLaunchKernelGGL((KER<T, false, true>), grid, block, 0, s, (T*)y, (const T*)bias, (const T*)residual, groups, channels);     \
+        else hipLaunchKernelGGL((KER<T, false, false>), grid, block, 0, s, (T*)y, (const T*)bias, (const T*)nullptr, groups, channels);                   \
+    } while (0)
+    if (dtype == VOSPROP_DT_BF16) VOSPROP_BA(bias_act_kernel, bf16_t);
+    else if (dtype == VOSPROP_DT_F16) VOSPROP_BA(bias_act_kernel, _Float16);
+    else if (dtype == VOSPROP_DT_F32) {
+        float* yf = (float*)y;
+        const float *bf = (const float*)bias, *rf = (const float*)residual;
+        if (relu && rf) hipLaunchKernelGGL((bias_act_f32_kernel<true, true>), grid, block, 0, s, yf, bf, rf, groups, channels);
+        else if (relu) hipLaunchKernelGGL((bias_act_f32_kernel<true, false>), grid, block, 0, s, yf, bf, rf, groups, channels);
+        else if (rf) hipLaunchKernelGGL((bias_act_f32_kernel<false, true>), grid, block, 0, s, yf, bf, rf, groups, channels);
+        else hipLaunchKernelGGL((bias_act_f32_kernel<false, false>), grid, block, 0, s, yf, bf, rf, groups, channels);
+    } else return VOSPROP_E_INVALID;
+#undef VOSPROP_BA
+    return hipGetLastError() == hipSuccess ? VOSPROP_OK : VOSPROP_E_HIP;
 }
 
 /* test hook (no GPU needed): segment table for TT target tiles x NT reference tiles; rows of out = (workgroup, tt, r_lo, n_steps) */

@@ -12,8 +12,39 @@ Differences, on purpose:
     the MI355X-friendly layout for the 1x1/3x3 convolutions.  The propagation step, not the encoder, is the
     hand-written HIP part of this project.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}     # VOSPROP_DT_*
+
+
+def bias_act_(y, bias, residual=None, relu=True):
+    """In place: y = act(y + bias[c] (+ residual)).  On the GPU one pass of the hand-written epilogue kernel
+    (vosprop_bias_act, csrc/encoder_ops.h) over the channels-last tensor; anywhere else the same thing with torch ops."""
+    if (y.is_cuda and y.dtype in _DT and y.dim() == 4 and y.shape[1] % 8 == 0 and bias.dtype == y.dtype
+            and y.is_contiguous(memory_format=torch.channels_last)
+            and (residual is None or (residual.dtype == y.dtype and residual.shape == y.shape
+                                      and residual.is_contiguous(memory_format=torch.channels_last)))):
+        from . import _native
+        rc = _native.lib().vosprop_bias_act(
+            ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+            ctypes.c_void_p(residual.data_ptr()) if residual is not None else None,
+            y.shape[0] * y.shape[2] * y.shape[3], y.shape[1], int(bool(relu)), _DT[y.dtype],
+            ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+        if rc != 0:
+            raise _native.VospropError(f'vosprop_bias_act failed ({rc})')
+        return y
+    y.add_(bias.view(1, -1, 1, 1))
+    if residual is not None:
+        y.add_(residual)
+    return y.relu_() if relu else y
+
+
+def _conv_nobias(x, conv):
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 # (block kind, blocks per stage) - reference resnet.py:159-216
 _ARCH = {
@@ -53,7 +84,23 @@ class ResidualUnit(nn.Module):
                                             nn.BatchNorm2d(cout))
         self.out_channels = cout
 
+    fused = False     # set by VOSNet.prepare_for_inference: BatchNorm folded, epilogues through bias_act_
+
+    def forward_fused(self, x):
+        """Same arithmetic with each convolution's bias / ReLU / residual add done in one pass (BatchNorm must be folded)."""
+        if self.downsample is None:
+            skip, b_out = x, (self.conv3 if self.kind != 'basic' else self.conv2).bias
+        else:
+            skip, b_out = _conv_nobias(x, self.downsample[0]), self.bias_out
+        y = bias_act_(_conv_nobias(x, self.conv1), self.conv1.bias)
+        if self.kind == 'basic':
+            return bias_act_(_conv_nobias(y, self.conv2), b_out, skip)
+        y = bias_act_(_conv_nobias(y, self.conv2), self.conv2.bias)
+        return bias_act_(_conv_nobias(y, self.conv3), b_out, skip)
+
     def forward(self, x):
+        if self.fused:
+            return self.forward_fused(x)
         skip = x if self.downsample is None else self.downsample(x)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
@@ -102,7 +149,17 @@ class VOSNet(nn.Module):
                 nn.init.ones_(m.weight)
                 nn.init.zeros_(m.bias)
 
+    fused = False
+
     def forward(self, x):
+        if self.fused:
+            bb = self.backbone
+            x = bb[3](bias_act_(_conv_nobias(x, bb[0]), bb[0].bias))      # stem conv + folded BN + ReLU, max-pool
+            for stage in list(bb)[4:]:
+                x = stage(x)
+            if self.model != 'resnet18':
+                x = bias_act_(_conv_nobias(x, self.adjust_dim), self.adjust_dim.bias, None, relu=False)
+            return x
         x = self.backbone(x)
         if self.model != 'resnet18':
             x = self.bn256(self.adjust_dim(x))
@@ -139,15 +196,25 @@ class VOSNet(nn.Module):
             self.adjust_dim, self.bn256 = fold(self.adjust_dim, self.bn256), nn.Identity()
         return self
 
-    def prepare_for_inference(self, device, dtype=torch.bfloat16, fold_bn=True):
+    def prepare_for_inference(self, device, dtype=torch.bfloat16, fold_bn=True, fuse_epilogue=True):
         """eval + folded BatchNorm + channels_last + reduced-precision weights on `device` (the reference runs the
-        encoder under torch.cuda.amp.autocast = fp16 on GPU, inference_utils.py:35,52)."""
+        encoder under torch.cuda.amp.autocast = fp16 on GPU, inference_utils.py:35,52).  fuse_epilogue: bias + residual add +
+        ReLU after every convolution as one pass (bias_act_) instead of two or three element-wise kernels."""
         self.eval().to(device)
         if fold_bn:
             self.fold_batchnorm()
         if dtype is not None and dtype != torch.float32:
             self.to(dtype)
-        return self.to(memory_format=torch.channels_last)
+        self.to(memory_format=torch.channels_last)
+        if fold_bn and fuse_epilogue:
+            for stage in list(self.backbone)[4:]:
+                for u in stage:
+                    if u.downsample is not None:      # the shortcut's bias joins the last convolution's: one combined add
+                        last = u.conv3 if u.kind != 'basic' else u.conv2
+                        u.bias_out = (last.bias.detach().float() + u.downsample[0].bias.detach().float()).to(last.bias.dtype)
+                    u.fused = True
+            self.fused = True
+        return self
 
 
 class GraphedEncoder:
