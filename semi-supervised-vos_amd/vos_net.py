@@ -241,7 +241,9 @@ class GraphedEncoder:
                 self.net(self.x)
         torch.cuda.current_stream(x.device).wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), torch.no_grad():
+        # thread_local: calls made by other threads of the process (e.g. RCCL's watchdog under torch.distributed) must not
+        # invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode='thread_local'), torch.no_grad():
             self.y = self.net(self.x)
         self.graph, self.shape, self.dtype = g, tuple(x.shape), x.dtype
 

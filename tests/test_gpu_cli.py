@@ -80,3 +80,18 @@ def test_device_normalisation_equals_host_normalisation():
     host = ds.normalize_image(img)
     dev = ds.normalize_on_device(ds.raw_image(img)[None].cuda())[0].cpu()
     assert torch.equal(host, dev)
+
+
+def test_c_abi_standalone_driver(tmp_path):
+    """examples/cbench.cpp: a C++ program that only includes include/vosprop.h and links libvosprop.so (no Python, no torch in the
+    process) runs a 480p clip through begin_video / step / time_last_propagation."""
+    exe = tmp_path / 'cbench'
+    lib_dir = ROOT / 'semi-supervised-vos_amd'
+    build = subprocess.run(['hipcc', '-O2', '--offload-arch=gfx950', f'-I{ROOT / "include"}', str(ROOT / 'examples' / 'cbench.cpp'),
+                            f'-L{lib_dir}', '-lvosprop', '-o', str(exe)], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    import os
+    env = dict(os.environ, LD_LIBRARY_PATH=f'{lib_dir}:' + os.environ.get('LD_LIBRARY_PATH', ''))
+    run = subprocess.run([str(exe), '24'], capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert 'kernel' in run.stdout and 'N=9' in run.stdout
