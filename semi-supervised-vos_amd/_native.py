@@ -57,7 +57,9 @@ SYMBOLS = {
     'vosprop_time_last_propagation': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_double)]),
 }
 
-HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared']
+# -fno-slp-vectorize: packed f32 VALU instructions do not overlap with MFMAs on gfx950 (tools/ubench_slot.hip); without the
+# flag hipcc packs the softmax sums into v_pk_add_f32 and the shipped kernel is 5 % slower (measured)
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize']
 
 
 def build(force=False, verbose=False):

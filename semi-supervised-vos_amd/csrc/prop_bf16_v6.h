@@ -41,7 +41,27 @@ constexpr int kW6 = 4;
 constexpr int kRing6 = 4;
 constexpr float kSumThr = 256.0f;   // 2^kRescaleThr
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Two floats handled as TWO SCALARS on purpose.  Packed f32 instructions (v_pk_fma_f32, v_pk_add_f32, v_pk_mul_f32) do not
+// overlap with MFMAs on gfx950 - they behave as if they ran on the matrix pipe: {MFMA ; 4 packed ops} costs 66 cycles per slot,
+// {MFMA ; add, add, exp, exp, fma, fma} costs 45 (tools/ubench_slot.hip).  A real 2-vector type would be selected as packed
+// instructions, so this is a struct, and the library is built with -fno-slp-vectorize so that hipcc does not pack scalars again.
+struct f32x2 {
+    float v[2];
+    __device__ __forceinline__ float& operator[](int i) { return v[i]; }
+    __device__ __forceinline__ const float& operator[](int i) const { return v[i]; }
+    __device__ __forceinline__ f32x2& operator+=(const f32x2& o) {
+        v[0] += o.v[0];
+        v[1] += o.v[1];
+        return *this;
+    }
+};
+__device__ __forceinline__ f32x2 v6_fma2(const f32x2& a, const f32x2& b, const f32x2& c) {
+    f32x2 r;
+    r.v[0] = __builtin_fmaf(a.v[0], b.v[0], c.v[0]);
+    r.v[1] = __builtin_fmaf(a.v[1], b.v[1], c.v[1]);
+    return r;
+}
+#define V6_PIN2(x) asm volatile("" : "+v"((x).v[0]), "+v"((x).v[1]))
 
 // Every group of MFMAs is ONE asm statement: hipcc cannot see that the statements are matrix instructions, so any register
 // copy it drops between two of them would sit inside their hazard windows.  Each statement starts with the wait states a
@@ -103,7 +123,7 @@ __device__ __forceinline__ void v6_pair_den(const V6Tile& u, V6Soft& s, int i, f
     f32x2 sv;
     sv[0] = u.S[cb][r];
     sv[1] = u.S[cb][r + 1];
-    const f32x2 x = sv * c2 + nmc[cb];
+    const f32x2 x = v6_fma2(sv, c2, nmc[cb]);
     f32x2 e;
     e[0] = __builtin_amdgcn_exp2f(x[0]);
     e[1] = __builtin_amdgcn_exp2f(x[1]);
@@ -114,7 +134,7 @@ __device__ __forceinline__ void v6_pair_num(const V6Sw& sw, V6Soft& s, int i, f3
     f32x2 wv;
     wv[0] = sw.w[cb][r];
     wv[1] = sw.w[cb][r + 1];
-    const f32x2 y = wv * c2 + nmq[cb];
+    const f32x2 y = v6_fma2(wv, c2, nmq[cb]);
     const float p0 = __builtin_amdgcn_exp2f(y[0]);
     const float p1 = __builtin_amdgcn_exp2f(y[1]);
     s.pk[cb][r >> 3][r & 7] = (bf16_t)p0;
@@ -128,14 +148,14 @@ __device__ __forceinline__ f32x2 v6_den_a(const V6Tile& u, int i, f32x2 c2, cons
     f32x2 sv;
     sv[0] = u.S[cb][r];
     sv[1] = u.S[cb][r + 1];
-    return sv * c2 + nmc[cb];
+    return v6_fma2(sv, c2, nmc[cb]);
 }
 __device__ __forceinline__ f32x2 v6_num_a(const V6Sw& sw, int i, f32x2 c2, const f32x2 (&nmq)[2]) {
     const int cb = i >> 3, r = 2 * (i & 7);
     f32x2 wv;
     wv[0] = sw.w[cb][r];
     wv[1] = sw.w[cb][r + 1];
-    return wv * c2 + nmq[cb];
+    return v6_fma2(wv, c2, nmq[cb]);
 }
 __device__ __forceinline__ f32x2 v6_exp2(f32x2 x) {
     f32x2 e;
@@ -411,12 +431,15 @@ __global__ __launch_bounds__(kW6 * 64, 1) void prop_bf16_v6_kernel(const PropArg
                     // order inside the slot: add (pair ks-1), exps (pair ks), fma (pair ks+1).  Each empty asm "redefines" the
                     // input of the next stage, so the stages cannot be hoisted over one another
                     if (ks > 0) sf.l[(ks - 1) >> 3] += ep;
-                    asm volatile("" : "+v"(sf.l[0]), "+v"(sf.l[1]), "+v"(xn));
+                    V6_PIN2(sf.l[0]);
+                    V6_PIN2(sf.l[1]);
+                    V6_PIN2(xn);
                     f32x2 e = v6_exp2(xn);
-                    asm volatile("" : "+v"(e), "+v"(nmc[(ks < 15 ? ks + 1 : ks) >> 3]));
+                    V6_PIN2(e);
+                    V6_PIN2(nmc[(ks < 15 ? ks + 1 : ks) >> 3]);
                     if (ks < 15) {
                         xn = v6_den_a(prev, ks + 1, c2, nmc);
-                        asm volatile("" : "+v"(xn));
+                        V6_PIN2(xn);
                     }
                     ep = e;
                 }
@@ -442,13 +465,15 @@ __global__ __launch_bounds__(kW6 * 64, 1) void prop_bf16_v6_kernel(const PropArg
                 if (SM && !(V6_ABLATE & 4)) {
                     if (ks > 0) {
                         v6_num_c(sf, ks - 1, pp);
-                        asm volatile("" : "+v"(sf.pk[(ks - 1) >> 3][((ks - 1) >> 2) & 1]), "+v"(yn));
+                        asm volatile("" : "+v"(sf.pk[(ks - 1) >> 3][((ks - 1) >> 2) & 1]));
+                        V6_PIN2(yn);
                     }
                     f32x2 pe = v6_exp2(yn);
-                    asm volatile("" : "+v"(pe), "+v"(nmq[(ks < 15 ? ks + 1 : ks) >> 3]));
+                    V6_PIN2(pe);
+                    V6_PIN2(nmq[(ks < 15 ? ks + 1 : ks) >> 3]);
                     if (ks < 15) {
                         yn = v6_num_a(Sw, ks + 1, c2, nmq);
-                        asm volatile("" : "+v"(yn));
+                        V6_PIN2(yn);
                     }
                     pp = pe;
                 }
