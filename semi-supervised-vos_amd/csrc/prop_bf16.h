@@ -61,7 +61,8 @@ constexpr int kOffCoord = kLdsFeat;
 constexpr int kOffLabHi = kLdsFeat + kLdsCoord;
 constexpr int kOffLabLo = kOffLabHi + kLdsLab;
 constexpr int kLdsBuf = kOffLabLo + kLdsLab;      // 22528
-constexpr int kRing = 3;
+constexpr int kRing = 3;                          // v5 kernel
+constexpr int kRing4 = 4;                         // shipped kernel: tiles are staged THREE steps ahead (see the main loop)
 constexpr int kGlbFeat = kTileR * kC * 2;         // 16384 bytes of one tile in HBM
 constexpr float kRescaleThr = 8.0f;               // defer-max threshold in log2 units (p <= 2^8)
 constexpr float kNegBig = -1.0e30f;
@@ -123,9 +124,9 @@ struct AFrag {
 // 16 + 1 MFMAs: S = R.T over the 256 channels, Sw = S + spatial term.  The first 8 fragments were prefetched during the
 // previous softmax burst; each MFMA is followed by the ds_read_b128 (immediate offset) that refills its slot with the
 // fragment 8 steps ahead, so the chain never waits on LDS.
-template <bool PROB>
+template <bool PROB, typename Hook>
 __device__ __forceinline__ void tile_scores(const unsigned char* lb, int j, int h, const bf16x8 (&Bt)[16],
-                                            const bf16x8& Bx, AFrag<PROB>& f, f32x16& S, f32x16& Sw) {
+                                            const bf16x8& Bx, AFrag<PROB>& f, f32x16& S, f32x16& Sw, Hook&& hook) {
     const unsigned char* arow = lb + j * kRowB + h * 16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[r] = 0.0f;
@@ -143,9 +144,13 @@ __device__ __forceinline__ void tile_scores(const unsigned char* lb, int j, int 
     for (int ks = 0; ks < 8; ++ks) {
         S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks], Bt[ks], S, 0, 0, 0);
         f.a[ks] = *(const bf16x8*)(arow + (ks + 8) * 32);
+        hook(ks);
     }
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks], Bt[ks + 8], S, 0, 0, 0);
+    for (int ks = 0; ks < 8; ++ks) {
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[ks], Bt[ks + 8], S, 0, 0, 0);
+        hook(ks + 8);
+    }
 #endif
     if (!PROB) Sw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ax, Bx, S, 0, 0, 0);
 }
@@ -352,7 +357,7 @@ __device__ __forceinline__ void tile_topk_pass2(f32x16& S, f32x16& Sw, float mc,
 
 template <bool PROB, bool LAB_LO, int MODE>
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArgs A) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kRing * kLdsBuf];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kRing4 * kLdsBuf];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -470,42 +475,64 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             stile = (r_lo + step) - sn * TPF;
             stage_frame();
         };
-        auto stage_issue = [&](int buf) {   // fetch the staging cursor's tile straight into ring slot `buf`
-            typedef __attribute__((address_space(3))) void* lds_ptr;
-            typedef const __attribute__((address_space(1))) void* glb_ptr;
+        // Every wave issues exactly THREE pieces per tile (constant s_waitcnt count): two feature pieces and a third one by
+        // role - wave 0 feature piece 16, wave 1 coordinates, waves 2-3 label hi, waves 4-5 label lo; waves without a third
+        // piece of their own (6, 7, and 1 / 4 / 5 in the modes that have no such data) repeat their first feature piece.
+        // The pieces are issued one at a time from inside the MFMA burst (stage_piece), not in a burst of their own: back to
+        // back they cost ~150 cycles of issue each (the vector-memory queue fills), spread out ~40.
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        auto stage_piece = [&](int buf, int i) {   // i = 0, 1, 2
             unsigned char* lds = smem + buf * kLdsBuf;
             const unsigned char* f = f_base + (size_t)stile * kGlbFeat;
-            __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_a), (lds_ptr)(lds + wave * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_b), (lds_ptr)(lds + (wave + 8) * 1024), 16, 0, 0);
-            if (wave == 0) {
+            if (i == 0) {
+                __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_a), (lds_ptr)(lds + wave * 1024), 16, 0, 0);
+            } else if (i == 1) {
+                __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_b), (lds_ptr)(lds + (wave + 8) * 1024), 16, 0, 0);
+            } else if (wave == 0) {
                 __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_c), (lds_ptr)(lds + 16 * 1024), 16, 0, 0);
-            } else if (wave == 1) {
-                if (!PROB)
-                    __builtin_amdgcn_global_load_lds((glb_ptr)((const unsigned char*)A.coord_tab + (size_t)stile * kLdsCoord + lane * 16),
-                                                     (lds_ptr)(lds + kOffCoord), 16, 0, 0);
-            } else if (wave <= 3) {
+            } else if (wave == 1 && !PROB) {
+                __builtin_amdgcn_global_load_lds((glb_ptr)((const unsigned char*)A.coord_tab + (size_t)stile * kLdsCoord + lane * 16),
+                                                 (lds_ptr)(lds + kOffCoord), 16, 0, 0);
+            } else if (wave == 2 || wave == 3) {
                 __builtin_amdgcn_global_load_lds((glb_ptr)(lh_base + (size_t)stile * kLdsLab + (wave - 2) * 1024 + lane * 16),
                                                  (lds_ptr)(lds + kOffLabHi + (wave - 2) * 1024), 16, 0, 0);
-            } else if (wave <= 5) {
-                if (LAB_LO)
-                    __builtin_amdgcn_global_load_lds((glb_ptr)(ll_base + (size_t)stile * kLdsLab + (wave - 4) * 1024 + lane * 16),
-                                                     (lds_ptr)(lds + kOffLabLo + (wave - 4) * 1024), 16, 0, 0);
-            }
-            if (++stile == TPF) {
-                asm volatile("; next staged frame" ::: "memory");
-                stile = 0;
-                ++sn;
-                if (sn < A.n_ref) stage_frame();
+            } else if ((wave == 4 || wave == 5) && LAB_LO) {
+                __builtin_amdgcn_global_load_lds((glb_ptr)(ll_base + (size_t)stile * kLdsLab + (wave - 4) * 1024 + lane * 16),
+                                                 (lds_ptr)(lds + kOffLabLo + (wave - 4) * 1024), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_a), (lds_ptr)(lds + wave * 1024), 16, 0, 0);
             }
         };
-        auto stage_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+        auto stage_advance = [&]() {   // next tile of the reference stream; stays on the last one at the end of the stream
+            int ns = stile + 1, nn = sn;
+            if (ns == TPF) {
+                ns = 0;
+                nn = sn + 1;
+            }
+            if (nn < A.n_ref) {
+                stile = ns;
+                if (nn != sn) {
+                    asm volatile("; next staged frame" ::: "memory");
+                    sn = nn;
+                    stage_frame();
+                }
+            }
+        };
+        auto stage_issue = [&](int buf) {
+            stage_piece(buf, 0);
+            stage_piece(buf, 1);
+            stage_piece(buf, 2);
+            stage_advance();
+        };
         (void)f_off;
 
-        // prologue: tiles 0 and 1 by everyone
+        // prologue: tiles 0, 1, 2 by everyone (past the end of a short segment: tiles nobody reads)
         stage_seek(0);
         stage_issue(0);
-        if (n_steps > 1) stage_issue(1);
-        stage_wait();
+        stage_issue(1);
+        stage_issue(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (grpB) __syncthreads();
 
@@ -520,29 +547,34 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
 
         AFrag<PROB> fr;
         fr.prefetch(smem, j, h);
-        int b_cur = 0, b_nxt = 1, b_st = 2;
 #ifndef VOSPROP_PRIO_MODE
 #define VOSPROP_PRIO_MODE 2   // 2 = score (MFMA) burst at priority 1: -3.5 % measured; 1 = younger wave group at priority 1: null; 0 = off
 #endif
         if (VOSPROP_PRIO_MODE == 1 && grpB) __builtin_amdgcn_s_setprio(1);
         for (int p = 0; p < n_steps; ++p) {
-            const bool have_st = (VOSPROP_ABLATE & 4) ? false : (p + 2 < n_steps);
-            const unsigned char* lb = smem + b_cur * kLdsBuf;
+            // Tile t sits in ring slot t & 3.  Step p scores tile p, prefetches tile p+1, stages tile p+3 (three pieces per wave,
+            // issued inside the MFMA burst) and ends by waiting for ITS pieces of tile p+2 - issued a whole step earlier, so the
+            // wait is normally free (with a 3-slot ring and a wait for the pieces issued in the same step it cost ~230 cycles).
+            const unsigned char* lb = smem + (p & 3) * kLdsBuf;
+            const unsigned char* lbn = smem + ((p + 1) & 3) * kLdsBuf;
+            const int b_st = (p + 3) & 3;
             STAMP_AT(0);   // bucket 0: loop overhead (+ time between segments)
             // ---- scores(p) ----
-            if (have_st) stage_issue(b_st);
             LabFrag<LAB_LO> lab;
             if (MODE == 0) lab.load(lb, lane);
-            STAMP_AT(1);   // 1: issue of the LDS-DMA pieces + label reads
+            STAMP_AT(1);   // 1: label reads
             f32x16 S, Sw;
             if (VOSPROP_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
-            tile_scores<PROB>(lb, j, h, Bt, sparse ? Bx2 : Bx1, fr, S, Sw);
+            tile_scores<PROB>(lb, j, h, Bt, sparse ? Bx2 : Bx1, fr, S, Sw, [&](int ks) {
+                if (!(VOSPROP_ABLATE & 4) && (ks == 2 || ks == 7 || ks == 12)) stage_piece(b_st, ks / 5);
+            });
+            if (!(VOSPROP_ABLATE & 4)) stage_advance();
             if (VOSPROP_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(0);
             STAMP_AT(2);   // 2: MFMA chain
             if (!(VOSPROP_ABLATE & 8)) __syncthreads();
             STAMP_AT(3);   // 3: barrier 1
             // ---- softmax(p) ----
-            fr.prefetch_lo(smem + b_nxt * kLdsBuf, j, h);   // first fragments of tile p+1 (harmless when p+1 == n_steps)
+            fr.prefetch_lo(lbn, j, h);   // first fragments of tile p+1 (harmless when p+1 == n_steps)
             STAMP_AT(4);   // 4: prefetch issue   (5: max + rescale decision, 6: exps + sums inside tile_softmax)
             const bool tail = ragged && ctile == TPF - 1;
             if (MODE == 0) {
@@ -554,8 +586,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
                                 (unsigned)(cn * A.HWp + ctile * kTileR), t, A);
             }
             STAMP_AT(7);   // 7: pack + label MFMAs
-            fr.prefetch_hi(smem + b_nxt * kLdsBuf, j, h);
-            stage_wait();   // this wave's pieces of tile p+2 have landed (issued a whole step ago)
+            fr.prefetch_hi(lbn, j, h);
+            // this wave's pieces of tile p+2 have landed; the 3 of tile p+3 may stay in flight (loads return in order).  Top-k
+            // pass 2 also issues atomics and stores, which share the counter: it waits for everything
+            if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             if (++ctile == TPF) {   // the next tile starts a new reference frame: its sigma may differ
                 asm volatile("; next scored frame" ::: "memory");
                 ctile = 0;
@@ -564,13 +599,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
                 kq = sparse ? kq2 : kq1;
             }
             STAMP_AT(8);   // 8: DMA wait + frame bookkeeping
+            // (barrier 2 was also tried BEFORE the tail - prefetch_hi, DMA wait, bookkeeping - to even out the two intervals of a
+            // step: 5 % slower; the two wave groups slow each other down, the sum of the work matters more than the longer phase)
             if (!(VOSPROP_ABLATE & 8)) __syncthreads();
             STAMP_AT(9);   // 9: barrier 2
-            const int tmp = b_cur;
-            b_cur = b_nxt;
-            b_nxt = b_st;
-            b_st = tmp;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the look-ahead pieces before the ring is re-staged
         if (!grpB) __syncthreads();
 #ifdef VOSPROP_STAMP
         if (A.dbg && lane == 0)
