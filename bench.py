@@ -106,14 +106,14 @@ def mask_parity(wl, cfg, ann, feats, gpu_masks, n_frames=7):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=160)
-    ap.add_argument('--warmup', type=int, default=16)
+    ap.add_argument('--steps', type=int, default=320)
+    ap.add_argument('--warmup', type=int, default=32)
     ap.add_argument('--workload', default='davis480p_r50_dense', choices=sorted(WORKLOADS))
     ap.add_argument('--encoder-dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-encoder-graph', action='store_true', help='run the encoder as eager kernel launches')
     ap.add_argument('--prime', type=int, default=20, help='untimed frames that fill the reference history')
-    ap.add_argument('--encoder-batch', type=int, default=16,
+    ap.add_argument('--encoder-batch', type=int, default=32,
                     help='frames encoded per encoder call (features do not depend on the propagated labels)')
     args = ap.parse_args()
 
@@ -140,7 +140,7 @@ def main():
     model_state = {k: v.clone() for k, v in net.state_dict().items()}
     net.prepare_for_inference(dev, enc_dtype)
     if not args.no_encoder_graph:
-        net = vos_net.GraphedEncoder(net)     # the batch-16 forward as one HIP graph launch
+        net = vos_net.GraphedEncoder(net, max_graphs=8)     # the look-ahead batch forward as one HIP graph launch per shape
 
     pool = 32                                    # distinct frames, cycled
     clip, ann = synthetic_clip(H, W, pool, seed=rank, device=dev)
@@ -186,10 +186,12 @@ def main():
         one_frame(fi, end=n_prime + args.warmup)
         fi += 1
     # the timed region encodes exactly the K frames it propagates: full batches of B and one tail batch of K % B frames.  Its
-    # shape is run once here, untimed, so that MIOpen's one-off algorithm search for a new batch size is not inside the timing
-    if args.steps % B:
+    # batch shapes are run once here, untimed, so that MIOpen's one-off algorithm search (and the HIP-graph capture) for a
+    # new batch size is not inside the timing
+    for n_warm in sorted({min(B, args.steps), args.steps % B} - {0}, reverse=True):
+        idx = torch.arange(n_warm, device=dev) % pool
         with torch.no_grad():
-            net(clip[:args.steps % B].contiguous(memory_format=torch.channels_last))
+            net(clip.index_select(0, idx).contiguous(memory_format=torch.channels_last))
     feat_buf['f'] = None   # the timed region starts with an empty look-ahead buffer: it pays for every frame it uses
     t_end = fi + args.steps
 
@@ -200,6 +202,7 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    eng.timing_begin()      # HIP events around every propagation-kernel launch of the timed region, on its stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         mask = one_frame(fi, end=t_end)
@@ -213,7 +216,8 @@ def main():
 
     # ---- dominant hand-written kernel alone: HIP events on the launch stream, N=9 propagation of the last step ----
     st = eng.last_stats()
-    prop_us = eng.time_last_propagation(iters=50)
+    prop_us, timed_launches = eng.timing_read()          # the kernel as it ran inside the timed loop
+    b2b_us = eng.time_last_propagation(iters=50)         # and re-run back to back (warm caches, steady clocks)
     achieved = st['flops'] / (prop_us * 1e-6) / 1e12
     # propagation-only frames/s (push + propagate + combine + label pack + mask), encoder excluded
     with torch.no_grad():
@@ -249,7 +253,8 @@ def main():
             'propagation_only_frames_per_s_per_gpu': prop_fps,
             'roofline': {'kernel': 'prop_bf16_kernel', 'bound': 'mfma', 'achieved': achieved,
                          'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us, 'flops_per_launch': st['flops'],
+                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us,
+                         'kernel_launches_timed': timed_launches, 'kernel_us_back_to_back': b2b_us, 'flops_per_launch': st['flops'],
                          'algorithmic_bytes_per_launch': st['bytes'], 'workgroups': st['workgroups']},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -163,6 +163,14 @@ int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out);
  * microseconds (bench.py's roofline.achieved).  Outputs are rewritten identically. */
 int vosprop_time_last_propagation(vosprop_ctx* ctx, int iters, void* stream, double* mean_us);
 
+/* In-situ timing of the propagation kernel: between vosprop_timing_begin and vosprop_timing_read every dense propagation launch of
+ * vosprop_step on ctx (label mode) carries a pair of HIP events attached to the dispatch itself on the launch stream
+ * (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps, no queue latency; at most 4096 launches are kept).  vosprop_timing_read waits for the recorded launches and returns their mean duration in microseconds and their
+ * number.  This is the kernel as it runs inside the loop (cold caches, neighbours on the stream) - what bench.py's
+ * roofline.achieved is computed from; vosprop_time_last_propagation gives the back-to-back figure. */
+int vosprop_timing_begin(vosprop_ctx* ctx);
+int vosprop_timing_read(vosprop_ctx* ctx, double* mean_us, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

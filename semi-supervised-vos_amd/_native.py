@@ -47,6 +47,8 @@ SYMBOLS = {
     'vosprop_begin_video_on': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), _vp]),
     'vosprop_begin_video_labels_on': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'vosprop_step': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, _vp, _vp]),
+    'vosprop_timing_begin': (ctypes.c_int, [_vp]),
+    'vosprop_timing_read': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     'vosprop_bias_act': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'vosprop_frame_index': (ctypes.c_int, [_vp]),
     'vosprop_predict': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -3,6 +3,7 @@
 #include "../../include/vosprop.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -70,6 +71,10 @@ struct vosprop_ctx {
     uint8_t* stage_host = nullptr; // pinned (HWp): first labels of a video on their way to the GPU (stream-ordered upload)
     hipEvent_t stage_ev = nullptr;
     bool stage_busy = false;
+    // in-situ kernel timing (vosprop_timing_begin / _read): event pairs around every propagation-kernel launch
+    bool timing = false;
+    std::vector<hipEvent_t> tev;   // pairs (start, stop), created on demand
+    size_t tev_used = 0;
     float* tk_thr = nullptr;       // top-k scratch (allocated when cfg.topk > 0)
     float* tk_m = nullptr;
     unsigned* tk_cnt = nullptr;
@@ -284,7 +289,10 @@ int push_features(vosprop_ctx* ctx, const void* src, int dtype, bf16_t* dst, hip
     return VOSPROP_OK;
 }
 
-void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream_t s) {
+// e0 / e1 (optional): HIP events attached to the dispatch itself (hipExtLaunchKernelGGL) - they carry the kernel's own start and
+// end timestamps, like a profiler's, without the queue latency a pair of hipEventRecord calls around the launch would include
+void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream_t s, hipEvent_t e0 = nullptr,
+                      hipEvent_t e1 = nullptr) {
     const dim3 grid(lp.grid), block(kWaves * 64);
     if (mode == 1) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 1>), grid, block, 0, s, a); return; }
     if (mode == 2) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 2>), grid, block, 0, s, a); return; }
@@ -307,13 +315,14 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream
         else hipLaunchKernelGGL((prop_bf16_kernel<true, false, 0>), grid, block, 0, s, a);
     } else {
         if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<false, true, 0>), grid, block, 0, s, a);
+        else if (e0) hipExtLaunchKernelGGL((prop_bf16_kernel<false, false, 0>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((prop_bf16_kernel<false, false, 0>), grid, block, 0, s, a);
     }
 }
 
 // The propagation kernel(s) of one step: dense = one launch; top-k = pass 1, select, pass 2.
-void launch_prop(const vosprop_ctx* ctx, const LastProp& lp, hipStream_t s) {
-    if (lp.topk == 0) { launch_prop_mode(lp, lp.args, 0, s); return; }
+void launch_prop(const vosprop_ctx* ctx, const LastProp& lp, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if (lp.topk == 0) { launch_prop_mode(lp, lp.args, 0, s, e0, e1); return; }
     PropArgs a1 = lp.args;
     a1.part_rows = lp.rows_pass1;
     launch_prop_mode(lp, a1, 1, s);
@@ -376,7 +385,18 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.tk_m = ctx->tk_m;
     a.tk_cnt = ctx->tk_cnt;
     a.tk_cand = ctx->tk_cand;
-    launch_prop(ctx, lp, s);
+    const bool timed = ctx->timing && !topk && !prob && !lab_lo && ctx->tev_used + 2 <= 2 * 4096;
+    if (timed) {
+        while (ctx->tev.size() < ctx->tev_used + 2) {
+            hipEvent_t e;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->tev.push_back(e);
+        }
+        launch_prop(ctx, lp, s, ctx->tev[ctx->tev_used], ctx->tev[ctx->tev_used + 1]);
+        ctx->tev_used += 2;
+    } else {
+        launch_prop(ctx, lp, s);
+    }
     HIP_TRY(ctx, hipGetLastError());
     const dim3 cgrid(ctx->HWp / 64 + (ctx->HWp % 64 ? 1 : 0));
     if (topk) {
@@ -590,6 +610,7 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     if (ctx->cls_tmp) (void)hipFree(ctx->cls_tmp);
     if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
     if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
+    for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
     if (ctx->tk_thr) (void)hipFree(ctx->tk_thr);
     if (ctx->tk_m) (void)hipFree(ctx->tk_m);
     if (ctx->tk_cnt) (void)hipFree(ctx->tk_cnt);
@@ -751,6 +772,31 @@ int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out) {
     if (!ctx || !out) return VOSPROP_E_INVALID;
     if (!ctx->last.valid) return VOSPROP_E_STATE;
     *out = ctx->stats;
+    return VOSPROP_OK;
+}
+
+int vosprop_timing_begin(vosprop_ctx* ctx) {
+    if (!ctx) return VOSPROP_E_INVALID;
+    ctx->timing = true;
+    ctx->tev_used = 0;
+    return VOSPROP_OK;
+}
+
+int vosprop_timing_read(vosprop_ctx* ctx, double* mean_us, int* launches) {
+    if (!ctx || !mean_us || !launches) return fail(ctx, VOSPROP_E_INVALID, "bad arguments");
+    ctx->timing = false;
+    double sum = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < ctx->tev_used; i += 2) {
+        HIP_TRY(ctx, hipEventSynchronize(ctx->tev[i + 1]));
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->tev[i], ctx->tev[i + 1]));
+        sum += (double)ms * 1000.0;
+        ++n;
+    }
+    ctx->tev_used = 0;
+    *mean_us = n ? sum / n : 0.0;
+    *launches = n;
     return VOSPROP_OK;
 }
 

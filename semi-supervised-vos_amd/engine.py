@@ -162,6 +162,16 @@ class PropagationEngine:
         self._check(self._L.vosprop_last_stats(self._ctx, ctypes.byref(st)), 'vosprop_last_stats')
         return {k: getattr(st, k) for k, _ in st._fields_}
 
+    def timing_begin(self):
+        """Start bracketing every dense propagation-kernel launch with HIP events on its stream (in-situ timing)."""
+        self._check(self._L.vosprop_timing_begin(self._ctx), 'vosprop_timing_begin')
+
+    def timing_read(self):
+        """-> (mean kernel duration in us, number of launches) since timing_begin(); waits for those launches."""
+        us, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        self._check(self._L.vosprop_timing_read(self._ctx, ctypes.byref(us), ctypes.byref(n)), 'vosprop_timing_read')
+        return us.value, n.value
+
     def time_last_propagation(self, iters=20):
         """Mean duration (us) of the propagation kernel alone, HIP events on the launch stream."""
         us = ctypes.c_double(0.0)

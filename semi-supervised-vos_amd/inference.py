@@ -54,7 +54,7 @@ _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
 @click.option('--gpus', type=int, default=1, help='[engine] GPUs of this node to shard the videos over.')
 @click.option('--encoder-dtype', type=click.Choice(sorted(_DTYPES)), default='bf16',
               help='[engine] encoder precision (the reference runs it under fp16 autocast on GPU).')
-@click.option('--encoder-batch', type=int, default=16, help='[engine] frames per encoder call (look-ahead).')
+@click.option('--encoder-batch', type=int, default=32, help='[engine] frames per encoder call (look-ahead).')
 @click.option('--io-workers', type=int, default=None,
               help='[engine] JPEG decode processes (default: min(8, cores - 1); the reference uses 1).')
 @click.option('--png-workers', type=int, default=2, help='[engine] PNG encoder threads.')
@@ -96,7 +96,7 @@ def _launch_shards(gpus):
 
 def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
-                           reduction, disable=False, encoder_dtype='bf16', shard=(0, 1), encoder_batch=16, io_workers=None,
+                           reduction, disable=False, encoder_dtype='bf16', shard=(0, 1), encoder_batch=32, io_workers=None,
                            png_workers=2, encoder_graph=True):
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)

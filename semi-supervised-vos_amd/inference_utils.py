@@ -90,7 +90,7 @@ def encoded_frames(model, loader, device, encoder_dtype, batch):
 
 def inference_single(model, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                      frame_range, ref_num, temperature, probability_propagation, disable, encoder_dtype=None,
-                     stats=None, encoder_batch=16, png_workers=2):
+                     stats=None, encoder_batch=32, png_workers=2):
     """stats (optional dict) receives {'frames', 'videos', 'seconds'} for the fps report."""
     import time
     from tqdm import tqdm
@@ -235,7 +235,7 @@ def fuse_two(a, b, probability, reduction_str, unflip):
 
 def _inference_two_branch(strategy, models, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                           frame_range, ref_num, temperature, probability_propagation, scale, reduction_str, disable,
-                          encoder_dtype=None, stats=None, encoder_batch=16, png_workers=2):
+                          encoder_dtype=None, stats=None, encoder_batch=32, png_workers=2):
     import time
     from tqdm import tqdm
     spec = _TWO_BRANCH[strategy]
@@ -326,7 +326,7 @@ def inference_multimodel(model, additional_model, inference_loader, total_len, a
 
 def inference_3_scale(model, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                       frame_range, ref_num, temperature, probability_propagation, scale, disable, encoder_dtype=None,
-                      stats=None, encoder_batch=16, output_size=THREE_SCALE_OUTPUT, png_workers=2):
+                      stats=None, encoder_batch=32, output_size=THREE_SCALE_OUTPUT, png_workers=2):
     """reference inference_utils.py:514-595: three full passes over the loader at input scales [0.9, 1.0, scale] (nearest
     pre-scaling of the normalised image), each a single chain whose class maps are produced at `output_size` (the
     reference hard-codes 480x910 whatever the video size); the saved mask is the element-wise maximum of the three class

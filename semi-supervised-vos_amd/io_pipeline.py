@@ -96,7 +96,7 @@ class ShmFrameLoader:
     decoders when that event has completed.  Frames whose byte size exceeds a slot (a larger video) are returned as ordinary
     tensors through the result queue."""
 
-    def __init__(self, dataset, workers=4, slots=64, register=True):
+    def __init__(self, dataset, workers=4, slots=128, register=True):
         import multiprocessing as mp
         from multiprocessing import shared_memory
         self.ds = dataset

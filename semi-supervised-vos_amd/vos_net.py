@@ -218,51 +218,57 @@ class VOSNet(nn.Module):
 
 
 class GraphedEncoder:
-    """The encoder forward for one fixed input shape captured in a HIP graph (torch.cuda.CUDAGraph): one graph launch instead
-    of ~330 eager kernel launches per batch - at 16 frames per call the eager launches cost the host ~14 ms, about the GPU time
-    of the whole batch, so the loop is host-bound without this.  Any other shape falls back to the eager module.
-    The output buffer is reused by the next call: consume (enqueue the readers of) one batch before asking for the next, on
-    the stream the graph is replayed on - which is how the frame loops use it."""
+    """The encoder forward captured in HIP graphs (torch.cuda.CUDAGraph), one per input shape (up to `max_graphs`: the full
+    look-ahead batch, the tail batch of a video, ...): one graph launch instead of ~330 eager kernel launches per batch - at
+    16-32 frames per call the eager launches cost the host about the GPU time of the whole batch, so the loop is host-bound
+    without this.  Shapes beyond the limit, CPU tensors and non-channels-last inputs run the eager module.
+    The output buffer of a shape is reused by the next call with that shape: consume (enqueue the readers of) one batch before
+    asking for the next, on the stream the graph is replayed on - which is how the frame loops use it."""
 
-    def __init__(self, net, warmup=3):
+    def __init__(self, net, warmup=3, max_graphs=4):
         self.net = net
         self.warmup = warmup
-        self.shape = self.dtype = None
-        self.graph = self.x = self.y = None
+        self.max_graphs = max_graphs
+        self.graphs = {}           # (shape, dtype) -> (graph, static input, static output)
         self.failed = False
+
+    @property
+    def graph(self):               # any captured graph (tests / introspection)
+        return next(iter(self.graphs.values()))[0] if self.graphs else None
 
     def _capture(self, x):
         s = torch.cuda.Stream(x.device)
         s.wait_stream(torch.cuda.current_stream(x.device))
-        self.x = torch.empty_like(x)          # keeps memory format (channels_last)
-        self.x.copy_(x)
+        xs = torch.empty_like(x)           # keeps memory format (channels_last)
+        xs.copy_(x)
         with torch.cuda.stream(s), torch.no_grad():
-            for _ in range(self.warmup):      # MIOpen's algorithm search and workspace growth happen here, outside the capture
-                self.net(self.x)
+            for _ in range(self.warmup):   # MIOpen's algorithm search and workspace growth happen here, outside the capture
+                self.net(xs)
         torch.cuda.current_stream(x.device).wait_stream(s)
         g = torch.cuda.CUDAGraph()
         # thread_local: calls made by other threads of the process (e.g. RCCL's watchdog under torch.distributed) must not
         # invalidate the capture
         with torch.cuda.graph(g, capture_error_mode='thread_local'), torch.no_grad():
-            self.y = self.net(self.x)
-        self.graph, self.shape, self.dtype = g, tuple(x.shape), x.dtype
+            ys = self.net(xs)
+        self.graphs[(tuple(x.shape), x.dtype)] = (g, xs, ys)
 
     def __call__(self, x):
-        if not x.is_cuda or self.failed:
+        if not x.is_cuda or self.failed or not x.is_contiguous(memory_format=torch.channels_last):
             return self.net(x)
-        if self.graph is None:
+        key = (tuple(x.shape), x.dtype)
+        if key not in self.graphs:
+            if len(self.graphs) >= self.max_graphs:
+                return self.net(x)
             try:
                 self._capture(x)
-            except Exception:                 # capture is an optimisation: never a reason to fail the run
+            except Exception:              # capture is an optimisation: never a reason to fail the run
                 self.failed = True
-                self.graph = None
                 torch.cuda.synchronize()
                 return self.net(x)
-        if tuple(x.shape) != self.shape or x.dtype != self.dtype or not x.is_contiguous(memory_format=torch.channels_last):
-            return self.net(x)
-        self.x.copy_(x)
-        self.graph.replay()
-        return self.y
+        g, xs, ys = self.graphs[key]
+        xs.copy_(x)
+        g.replay()
+        return ys
 
     def eval(self):
         return self
