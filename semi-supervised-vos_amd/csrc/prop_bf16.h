@@ -66,6 +66,7 @@ constexpr int kRing4 = 4;                         // shipped kernel: tiles are s
 constexpr int kGlbFeat = kTileR * kC * 2;         // 16384 bytes of one tile in HBM
 constexpr float kRescaleThr = 8.0f;               // defer-max threshold in log2 units (p <= 2^8)
 constexpr float kNegBig = -1.0e30f;
+constexpr float kSumThrV3 = 256.0f;              // 2^kRescaleThr, threshold on a tile's partial denominator
 
 __device__ __forceinline__ float half_max(float x) {   // max(x[lane], x[lane ^ 32]) in every lane
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -171,22 +172,14 @@ __device__ __forceinline__ void tile_softmax(const LabFrag<LAB_LO>& lab, int h, 
         }
     }
     // Optimistic pass: exponentiate against the CURRENT running max; the running max is only raised (and this tile
-    // redone) when some score exceeds it by more than kRescaleThr - rare after the first tiles - so the max reduction is
-    // off the critical path: a depth-3 v_max3 tree that the scheduler interleaves with the exps.
+    // redone) when some score exceeds it by more than kRescaleThr - rare after the first tiles.  The test is on the tile's
+    // partial denominator (any term above 2^8, or an overflow, pushes the sum of 16 non-negative terms above 2^8; a false
+    // alarm only costs a redo) - no per-tile max reduction at all.
     float mc = st.m * c;
     float mq = mc + kq;
     float e[16], p[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) e[r] = __builtin_fmaf(S[r], c, -mc);
-    float t0, t1, t2, t3, t4, emax;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(e[0]), "v"(e[1]), "v"(e[2]));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t1) : "v"(e[3]), "v"(e[4]), "v"(e[5]));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t2) : "v"(e[6]), "v"(e[7]), "v"(e[8]));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(e[9]), "v"(e[10]), "v"(e[11]));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t4) : "v"(e[12]), "v"(e[13]), "v"(e[14]));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t0) : "v"(t0), "v"(t1), "v"(t2));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(t3), "v"(t4), "v"(e[15]));
-    asm("v_max_f32 %0, %1, %2" : "=v"(emax) : "v"(t0), "v"(t3));
     float l0 = 0.0f, l1 = 0.0f;   // two chains: halves the dependent-add latency
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -203,7 +196,7 @@ __device__ __forceinline__ void tile_softmax(const LabFrag<LAB_LO>& lab, int h, 
         l0 += pa;
         l1 += pb;
     }
-    if (__any(emax > kRescaleThr)) {
+    if (__any(l0 + l1 > kSumThrV3)) {
         // slow path: raise the running max (shared by the two half-waves of a column), rescale what was accumulated
         // against the old one exactly once, and redo this tile against the new one (cdna guide T13 hazard)
         asm volatile("; rescale" ::: "memory");
