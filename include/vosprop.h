@@ -41,6 +41,9 @@ extern "C" {
 #define VOSPROP_DT_F32 0
 #define VOSPROP_DT_F16 1
 #define VOSPROP_DT_BF16 2
+/* OR into a feature dtype: the tensor is channels-last, (H_d*W_d, C) pixel-major - what a channels_last encoder hands over, and the
+ * engine's own ring order (a bf16 push is then a plain copy).  Without it feature tensors are (C, H_d, W_d). */
+#define VOSPROP_LAYOUT_HWC 0x10
 
 /* arithmetic of the affinity contraction */
 #define VOSPROP_PREC_BF16 0 /* bf16 MFMA (v_mfma_f32_32x32x16_bf16), f32 accumulate - the fast path */
@@ -111,7 +114,8 @@ int vosprop_begin_video_labels_on(vosprop_ctx* ctx, const uint8_t* cls_lowres_ho
  *   frame i>0: prediction = predict(...) (:56-65, src/model/predict.py:19-71); new label =
  *              one-hot(argmax) or the prediction itself in probability mode (:67-70); history append
  *              (:71-72); nearest up-sample + argmax (:74-75).
- * feat_dev   (C, H_d, W_d) in NCHW order, element type feat_dtype (the encoder output features[0]).
+ * feat_dev   (C, H_d, W_d) in NCHW order - or (H_d*W_d, C) with VOSPROP_LAYOUT_HWC - element type feat_dtype (the encoder output
+ *            features[0]).
  * pred_out_dev  optional (d, H_d*W_d) f32 - the reference's `prediction` tensor.
  * mask_out_dev  optional (H, W) uint8    - the reference's per-frame mask (class indices).
  * The frame index is kept by the engine (0,1,2,... since begin_video). */

@@ -43,6 +43,17 @@ __global__ __launch_bounds__(256) void push_kernel(const T* __restrict__ src, bf
     }
 }
 
+// Pixel-major (channels-last) source: (HW, C) rows are already in ring order, only the element type changes.
+template <typename T>
+__global__ __launch_bounds__(256) void push_hwc_kernel(const T* __restrict__ src, bf16_t* __restrict__ dst, int n8) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)to_f32<T>(src[(size_t)i * 8 + e]);
+    *(bf16x8*)(dst + (size_t)i * 8) = o;
+}
+
 // Element (s, lane, e) of a label tile is L[class = lane & 31][row = 16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)]:
 // the A-operand order that matches an accumulator tile reused as the B operand (see prop_bf16.h).
 __device__ inline int lab_row(int s, int lane, int e) { return 16 * s + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3); }

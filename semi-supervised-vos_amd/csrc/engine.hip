@@ -279,6 +279,20 @@ void launch_push(const void* src, bf16_t* dst, int HW, hipStream_t s) {
 }
 
 int push_features(vosprop_ctx* ctx, const void* src, int dtype, bf16_t* dst, hipStream_t s) {
+    if (dtype & VOSPROP_LAYOUT_HWC) {   // channels-last source: rows are in ring order already
+        const int n8 = ctx->HW * kC / 8;
+        const dim3 grid((n8 + 255) / 256), block(256);
+        switch (dtype & ~VOSPROP_LAYOUT_HWC) {
+            case VOSPROP_DT_BF16:
+                HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)ctx->HW * kC * sizeof(bf16_t), hipMemcpyDeviceToDevice, s));
+                return VOSPROP_OK;
+            case VOSPROP_DT_F32: hipLaunchKernelGGL(push_hwc_kernel<float>, grid, block, 0, s, (const float*)src, dst, n8); break;
+            case VOSPROP_DT_F16: hipLaunchKernelGGL(push_hwc_kernel<__half>, grid, block, 0, s, (const __half*)src, dst, n8); break;
+            default: return fail(ctx, VOSPROP_E_INVALID, "unknown feature dtype");
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return VOSPROP_OK;
+    }
     switch (dtype) {
         case VOSPROP_DT_F32: launch_push<float>(src, dst, ctx->HW, s); break;
         case VOSPROP_DT_F16: launch_push<__half>(src, dst, ctx->HW, s); break;
@@ -445,7 +459,7 @@ int pack_labels_from_f32(vosprop_ctx* ctx, const float* L, size_t ld, int d, bf1
     return VOSPROP_OK;
 }
 
-size_t dtype_size(int dt) { return dt == VOSPROP_DT_F32 ? 4 : 2; }
+size_t dtype_size(int dt) { return (dt & ~VOSPROP_LAYOUT_HWC) == VOSPROP_DT_F32 ? 4 : 2; }
 
 // ATen nearest-neighbour source index (see aux_kernels.h upsample_kernel)
 inline int nearest_src(int dst, int in_size, int out_size) {

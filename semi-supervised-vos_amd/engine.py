@@ -11,6 +11,7 @@ from ._native import VospropError
 
 DT_CODES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 PREC_BF16, PREC_F32 = 0, 1
+LAYOUT_HWC = 0x10       # VOSPROP_LAYOUT_HWC
 SCALE = 0.125           # reference src/config.py:12
 CONTINUOUS_FRAME = 4    # reference src/config.py:13
 
@@ -120,7 +121,10 @@ class PropagationEngine:
             raise ValueError(f'features must be (256,{self.feat_h},{self.feat_w}), got {tuple(f.shape)}')
         if f.dtype not in DT_CODES:
             raise ValueError(f'unsupported feature dtype {f.dtype}')
-        f = f.contiguous()
+        # a slice of a channels_last batch is already pixel-major (H_d*W_d, C): hand it over as it is (VOSPROP_LAYOUT_HWC)
+        hwc = f.stride(0) == 1 and f.stride(2) == f.shape[0] and f.stride(1) == f.shape[0] * f.shape[2]
+        if not hwc:
+            f = f.contiguous()
         first = self.frame_index == 0
         pred = mask = None
         if not first:
@@ -128,7 +132,7 @@ class PropagationEngine:
                 pred = torch.empty((self.d, self.HW), dtype=torch.float32, device=self.device)
             if want_mask:
                 mask = torch.empty((self.H, self.W), dtype=torch.uint8, device=self.device)
-        rc = self._L.vosprop_step(self._ctx, ctypes.c_void_p(f.data_ptr()), DT_CODES[f.dtype],
+        rc = self._L.vosprop_step(self._ctx, ctypes.c_void_p(f.data_ptr()), DT_CODES[f.dtype] | (LAYOUT_HWC if hwc else 0),
                                   ctypes.c_void_p(pred.data_ptr()) if pred is not None else None,
                                   ctypes.c_void_p(mask.data_ptr()) if mask is not None else None,
                                   _stream_ptr(self.device))

@@ -234,3 +234,30 @@ def test_topk_rollout_vs_oracle(vos, dev):
     eng.close()
     with pytest.raises(vos.VospropError):
         vos.PropagationEngine(Hd, Wd, device=0, topk=20, probability=True)      # label-propagation mode only
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+def test_channels_last_features_are_taken_as_they_are(vos, dev, dtype):
+    """A (C,H_d,W_d) slice of a channels_last batch goes through VOSPROP_LAYOUT_HWC (no transposes); results equal the NCHW path."""
+    Hd, Wd, T = 12, 20, 7
+    g = torch.Generator().manual_seed(5)
+    batch = (torch.randn(T, 256, Hd, Wd, generator=g) * 0.25).to(dtype).to(dev)
+    cl = batch.contiguous(memory_format=torch.channels_last)
+    ann = np.zeros((Hd * 8, Wd * 8), np.uint8)
+    ann[: Hd * 4] = 1
+    ann[:, : Wd * 3] = 2
+    outs = []
+    for src in (batch, cl):
+        eng = vos.PropagationEngine(Hd, Wd, device=0)
+        eng.begin_video(ann)
+        preds = []
+        for t in range(T):
+            f = src[t]
+            assert f.is_contiguous() == (src is batch)
+            p, m = eng.step(f)
+            if p is not None:
+                preds.append((p.cpu(), m.cpu()))
+        outs.append(preds)
+        eng.close()
+    for (pa, ma), (pb, mb) in zip(*outs):
+        assert torch.equal(pa, pb) and torch.equal(ma, mb)
