@@ -112,6 +112,8 @@ def main():
     ap.add_argument('--encoder-dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-encoder-graph', action='store_true', help='run the encoder as eager kernel launches')
+    ap.add_argument('--no-miopen-find', action='store_true',
+                    help='take MIOpen\'s immediate-mode convolution algorithms instead of letting it time its solvers in the warm-up')
     ap.add_argument('--prime', type=int, default=20, help='untimed frames that fill the reference history')
     ap.add_argument('--encoder-batch', type=int, default=32,
                     help='frames encoded per encoder call (features do not depend on the propagated labels)')
@@ -138,7 +140,7 @@ def main():
     torch.manual_seed(0)
     net = vos_net.VOSNet(wl['model'])
     model_state = {k: v.clone() for k, v in net.state_dict().items()}
-    net.prepare_for_inference(dev, enc_dtype)
+    net.prepare_for_inference(dev, enc_dtype, miopen_find=not args.no_miopen_find)
     if not args.no_encoder_graph:
         net = vos_net.GraphedEncoder(net, max_graphs=8)     # the look-ahead batch forward as one HIP graph launch per shape
 

@@ -58,18 +58,21 @@ _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
 @click.option('--io-workers', type=int, default=None,
               help='[engine] JPEG decode processes (default: min(8, cores - 1); the reference uses 1).')
 @click.option('--png-workers', type=int, default=2, help='[engine] PNG encoder threads.')
+@click.option('--miopen-find/--no-miopen-find', default=False,
+              help='[engine] let MIOpen time its convolution solvers per batch shape (+16 % steady-state throughput, 10-20 s of '
+                   'search per shape at start-up: for long jobs).')
 @click.option('--encoder-graph/--no-encoder-graph', default=True,
               help='[engine] replay the encoder forward of full batches as one captured HIP graph.')
 @click.option('--shard', type=(int, int), default=(0, 1), hidden=True, help='[engine] internal: rank, world')
 def inference_command(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                       inference_strategy, additional_model, additional_model_type, probability, scale, fusion, gpus,
-                      encoder_dtype, encoder_batch, io_workers, png_workers, encoder_graph, shard):
+                      encoder_dtype, encoder_batch, io_workers, png_workers, miopen_find, encoder_graph, shard):
     if gpus > 1 and shard == (0, 1):
         return _launch_shards(gpus)
     inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_model, additional_model_type, probability, scale, fusion,
                            encoder_dtype=encoder_dtype, shard=shard, encoder_batch=encoder_batch, io_workers=io_workers,
-                           png_workers=png_workers, encoder_graph=encoder_graph)
+                           png_workers=png_workers, encoder_graph=encoder_graph, miopen_find=miopen_find)
 
 
 def _launch_shards(gpus):
@@ -97,7 +100,7 @@ def _launch_shards(gpus):
 def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
                            reduction, disable=False, encoder_dtype='bf16', shard=(0, 1), encoder_batch=32, io_workers=None,
-                           png_workers=2, encoder_graph=True):
+                           png_workers=2, encoder_graph=True, miopen_find=False):
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)
     if Config.DEVICE.type == 'cuda':
@@ -105,13 +108,13 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
     net = VOSNet(model=model)
     net = load_model(net, resume)
     dtype = _DTYPES[encoder_dtype] if Config.DEVICE.type == 'cuda' else None
-    net.prepare_for_inference(Config.DEVICE, dtype)
+    net.prepare_for_inference(Config.DEVICE, dtype, miopen_find=miopen_find)
     additional = None
     if inference_strategy == 'multimodel':      # reference src/inference.py:65-71
         if not additional_resume:
             raise click.UsageError("--inference-strategy multimodel needs --additional-model")
         additional = load_model(VOSNet(model=additional_model_type), additional_resume)
-        additional.prepare_for_inference(Config.DEVICE, dtype)
+        additional.prepare_for_inference(Config.DEVICE, dtype, miopen_find=miopen_find)
 
     if Config.DEVICE.type == 'cuda' and encoder_graph:
         # full batches of one resolution replay a captured HIP graph; everything else (last batch of a video, another

@@ -196,10 +196,17 @@ class VOSNet(nn.Module):
             self.adjust_dim, self.bn256 = fold(self.adjust_dim, self.bn256), nn.Identity()
         return self
 
-    def prepare_for_inference(self, device, dtype=torch.bfloat16, fold_bn=True, fuse_epilogue=True):
+    def prepare_for_inference(self, device, dtype=torch.bfloat16, fold_bn=True, fuse_epilogue=True, miopen_find=False):
         """eval + folded BatchNorm + channels_last + reduced-precision weights on `device` (the reference runs the
         encoder under torch.cuda.amp.autocast = fp16 on GPU, inference_utils.py:35,52).  fuse_epilogue: bias + residual add +
-        ReLU after every convolution as one pass (bias_act_) instead of two or three element-wise kernels."""
+        ReLU after every convolution as one pass (bias_act_) instead of two or three element-wise kernels.  miopen_find: let
+        MIOpen time its solvers for every new convolution shape (torch.backends.cudnn.benchmark, a process-wide switch) instead
+        of taking the immediate-mode pick - measured +16 % end to end at batch 32 on MI355X (1 225 -> 1 425 frames/s in
+        bench.py), but the search costs 10-20 s per new batch shape in every process (it is not cached across processes on this
+        stack), more than a whole DAVIS-sized job takes: off by default, on in bench.py (search in the untimed warm-up) and
+        with `main.py inference --miopen-find` for long jobs."""
+        if miopen_find and torch.device(device).type == 'cuda':
+            torch.backends.cudnn.benchmark = True
         self.eval().to(device)
         if fold_bn:
             self.fold_batchnorm()
