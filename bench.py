@@ -106,8 +106,8 @@ def mask_parity(wl, cfg, ann, feats, gpu_masks, n_frames=7):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=320)
-    ap.add_argument('--warmup', type=int, default=32)
+    ap.add_argument('--steps', type=int, default=384)
+    ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--workload', default='davis480p_r50_dense', choices=sorted(WORKLOADS))
     ap.add_argument('--encoder-dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -115,7 +115,7 @@ def main():
     ap.add_argument('--no-miopen-find', action='store_true',
                     help='take MIOpen\'s immediate-mode convolution algorithms instead of letting it time its solvers in the warm-up')
     ap.add_argument('--prime', type=int, default=20, help='untimed frames that fill the reference history')
-    ap.add_argument('--encoder-batch', type=int, default=32,
+    ap.add_argument('--encoder-batch', type=int, default=64,
                     help='frames encoded per encoder call (features do not depend on the propagated labels)')
     args = ap.parse_args()
 
