@@ -58,7 +58,10 @@ def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None):
             if encoder_dtype is not None:
                 x = x.to(encoder_dtype)
             with torch.no_grad():
-                feats.append(models[b](x.contiguous(memory_format=torch.channels_last)))
+                f = models[b](x.contiguous(memory_format=torch.channels_last))
+            if any(models[c] is models[b] for c in range(b + 1, nb)):
+                f = f.clone()       # a graph-replaying encoder reuses its output buffer: the next branch would overwrite it
+            feats.append(f)
         if hasattr(loader, 'recycle'):   # ShmFrameLoader: the slots may be reused once the copies have completed (one stream, in
             uniq = {id(t): t for b in range(nb) for t in pend[b]}     # order: the last event covers them all; 'multimodel'
             loader.recycle(list(uniq.values()), copied)               # shows the same tensor to both branches)

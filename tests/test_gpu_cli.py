@@ -95,3 +95,41 @@ def test_c_abi_standalone_driver(tmp_path):
     run = subprocess.run([str(exe), '24'], capture_output=True, text=True, timeout=600, env=env)
     assert run.returncode == 0, run.stdout + run.stderr
     assert 'kernel' in run.stdout and 'N=9' in run.stdout
+
+
+@pytest.mark.parametrize('strategy', ['hor-flip', '2-scale'])
+def test_inference_cli_strategy_matches_oracle(tmp_path, strategy):
+    """`main.py inference --inference-strategy ...` end to end (paired dataset items, two chains, GPU fusion, PNG output) against
+    the oracle's restatement of the same strategy fed with the same encoder's features."""
+    from PIL import Image, ImageOps
+    vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
+    ds = importlib.import_module('semi-supervised-vos_amd.datasets')
+    ann, frames = _make_dataset(tmp_path / 'data', n_frames=10)
+    torch.manual_seed(0)
+    net = vn.VOSNet('resnet18')
+    ckpt = tmp_path / 'ckpt.pth.tar'
+    torch.save({'state_dict': net.state_dict()}, ckpt)
+    scale = 1.25
+    out = subprocess.run([sys.executable, 'main.py', 'inference', '-d', str(tmp_path / 'data'), '-r', str(ckpt), '-m',
+                          'resnet18', '-s', str(tmp_path / 'out'), '--encoder-dtype', 'f32', '--ref_num', '5',
+                          '--frame_range', '6', '--inference-strategy', strategy, '--scale', str(scale)],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    net.eval().cuda()
+
+    def feats_of(imgs):
+        with torch.no_grad():
+            f = torch.cat([net(ds.normalize_image(im)[None].cuda()) for im in imgs])
+        return f.to(torch.bfloat16).float().cpu().numpy()        # the engine keeps features as bf16
+
+    for vid, arrs in frames.items():
+        imgs = [Image.fromarray(a) for a in arrs]
+        if strategy == 'hor-flip':
+            second = [ImageOps.mirror(im) for im in imgs]
+        else:
+            size2 = tuple(int(v) for v in np.ceil(np.array(imgs[0].size) * scale))
+            second = [im.resize(size2, Image.LANCZOS) for im in imgs]
+        want = vo.rollout_two_branch(strategy, ann, feats_of(imgs), feats_of(second), scale=scale, frame_range=6, ref_num=5)
+        got = np.stack([np.asarray(Image.open(tmp_path / 'out' / vid / f'{i:05d}.png')) for i in range(1, len(imgs))])
+        assert got.shape == want.shape
+        assert np.mean(got != want) <= 0.015, f'{vid}: {np.mean(got != want) * 100:.2f} % of pixels differ'
