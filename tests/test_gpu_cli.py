@@ -133,3 +133,49 @@ def test_inference_cli_strategy_matches_oracle(tmp_path, strategy):
         got = np.stack([np.asarray(Image.open(tmp_path / 'out' / vid / f'{i:05d}.png')) for i in range(1, len(imgs))])
         assert got.shape == want.shape
         assert np.mean(got != want) <= 0.015, f'{vid}: {np.mean(got != want) * 100:.2f} % of pixels differ'
+
+
+def test_inference_cli_multimodel_and_three_scale(tmp_path):
+    """The two remaining dispatch paths of the CLI: `multimodel` (second checkpoint, element-wise maximum of the two chains' class
+    maps) and `3-scale` (three passes, class maps at the reference's fixed 480x910, maximum of the three)."""
+    from PIL import Image
+    vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
+    ds = importlib.import_module('semi-supervised-vos_amd.datasets')
+    ann, frames = _make_dataset(tmp_path / 'data', n_frames=8)
+    nets = []
+    for i, seed in enumerate((0, 1)):
+        torch.manual_seed(seed)
+        nets.append(vn.VOSNet('resnet18'))
+        torch.save({'state_dict': nets[-1].state_dict()}, tmp_path / f'ckpt{i}.pth.tar')
+    common = [sys.executable, 'main.py', 'inference', '-d', str(tmp_path / 'data'), '-r', str(tmp_path / 'ckpt0.pth.tar'), '-m',
+              'resnet18', '--encoder-dtype', 'f32', '--ref_num', '5', '--frame_range', '6']
+    out = subprocess.run(common + ['-s', str(tmp_path / 'mm'), '--inference-strategy', 'multimodel', '--additional-model',
+                                   str(tmp_path / 'ckpt1.pth.tar'), '--additional-model-type', 'resnet18'],
+                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    out3 = subprocess.run(common + ['-s', str(tmp_path / 's3'), '--inference-strategy', '3-scale', '--scale', '1.25'],
+                          cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out3.returncode == 0, out3.stderr[-2000:]
+    for n in nets:
+        n.eval().cuda()
+
+    def feats_of(net, imgs, size=None):
+        with torch.no_grad():
+            xs = [ds.normalize_image(im)[None].cuda() for im in imgs]
+            if size is not None:
+                xs = [torch.nn.functional.interpolate(x, size=size, mode='nearest') for x in xs]
+            f = torch.cat([net(x) for x in xs])
+        return f.to(torch.bfloat16).float().cpu().numpy()
+
+    for vid, arrs in frames.items():
+        imgs = [Image.fromarray(a) for a in arrs]
+        want = vo.rollout_two_branch('multimodel', ann, feats_of(nets[0], imgs), feats_of(nets[1], imgs), frame_range=6, ref_num=5)
+        got = np.stack([np.asarray(Image.open(tmp_path / 'mm' / vid / f'{i:05d}.png')) for i in range(1, len(imgs))])
+        assert np.mean(got != want) <= 0.015, f'multimodel {vid}: {np.mean(got != want) * 100:.2f} % of pixels differ'
+        H, W = ann.shape
+        scales = (0.9, 1.0, 1.25)
+        f3 = [feats_of(nets[0], imgs, (int(np.ceil(H * s)), int(np.ceil(W * s)))) for s in scales]
+        want3 = vo.rollout_3_scale(ann, f3, scales, output_size=(480, 910), frame_range=6, ref_num=5)
+        got3 = np.stack([np.asarray(Image.open(tmp_path / 's3' / vid / f'{i:05d}.png')) for i in range(1, len(imgs))])
+        assert got3.shape == want3.shape == (len(imgs) - 1, 480, 910)
+        assert np.mean(got3 != want3) <= 0.02, f'3-scale {vid}: {np.mean(got3 != want3) * 100:.2f} % of pixels differ'
