@@ -79,8 +79,10 @@ def _launch_shards(gpus):
     """One child process per GPU (HIP_VISIBLE_DEVICES pins it); children never exec after touching the GPU."""
     argv = [a for a in sys.argv[1:]]
     procs = []
+    # VOSPROP_SHARD_DEVICES="0,0": device ordinal per shard (testing the sharded path on a box with fewer GPUs than shards)
+    devs = [d for d in os.environ.get('VOSPROP_SHARD_DEVICES', '').split(',') if d != '']
     for r in range(gpus):
-        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(r), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=devs[r % len(devs)] if devs else str(r), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, sys.argv[0]] + argv + ['--shard', str(r), str(gpus)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     frames, secs, rc = 0, 0.0, 0
