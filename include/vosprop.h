@@ -147,6 +147,17 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
 int vosprop_bias_act(void* y, const void* bias, const void* residual, long long pixels, int channels, int relu, int dtype,
                      void* stream);
 
+/* Pointwise (1x1, stride 1, no padding) convolution with its epilogue, context-free:
+ *     y[p, co] = act( sum_ci x[p, ci] * weight[co, ci] + bias[co] (+ residual[p, co]) )
+ * over channels-last tensors viewed as (pixels, channels) - conv1 / conv3 / downsample[0] of the reference's bottleneck units and
+ * `adjust_dim` together with the BatchNorm shift, `out += identity` and ReLU that follow them (src/model/backbone/resnet.py:66-95,
+ * src/model/vos_net.py:27-52) as ONE hipBLASLt GEMM (f32 accumulation) whose epilogue does the rest, so the output is written
+ * once.  x (pixels, cin), weight (cout, cin), bias (cout), residual / y (pixels, cout) share `dtype`; bias and residual may be
+ * NULL; residual may alias y.  The first call for a shape times the library's candidate algorithms on the operands (not inside a
+ * stream capture).  VOSPROP_E_UNSUPPORTED: the library has no kernel for the shape - use a convolution + vosprop_bias_act. */
+int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, const void* residual, void* y,
+                           long long pixels, int cin, int cout, int relu, int dtype, void* stream);
+
 /* Frame sampler, reference `sample_frames` (src/model/predict.py:74-89).  Host-side, exact.
  * out must hold num_refs ints (or frame_idx when frame_idx <= num_refs); returns the count. */
 int vosprop_sample_frames(int frame_idx, int frame_range, int num_refs, int* out);

@@ -50,6 +50,8 @@ SYMBOLS = {
     'vosprop_timing_begin': (ctypes.c_int, [_vp]),
     'vosprop_timing_read': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     'vosprop_bias_act': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    'vosprop_pointwise_conv': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, _vp]),
     'vosprop_frame_index': (ctypes.c_int, [_vp]),
     'vosprop_predict': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
@@ -62,6 +64,9 @@ SYMBOLS = {
 # -fno-slp-vectorize: packed f32 VALU instructions do not overlap with MFMAs on gfx950 (tools/ubench_slot.hip); without the
 # flag hipcc packs the softmax sums into v_pk_add_f32 and the shipped kernel is 5 % slower (measured)
 HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize']
+# hipBLASLt serves the encoder's pointwise convolutions (csrc/pointwise.h); in a torch process the copy torch has already loaded
+# (same SONAME) is the one that binds
+LINK_FLAGS = ['-L/opt/rocm/lib', '-lhipblaslt', '-Wl,-rpath,/opt/rocm/lib']
 
 
 def build(force=False, verbose=False):
@@ -71,7 +76,7 @@ def build(force=False, verbose=False):
         if all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
             return LIB_PATH
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    cmd = [hipcc] + HIPCC_FLAGS + ['-o', str(LIB_PATH), str(_SRC / 'engine.hip')]
+    cmd = [hipcc] + HIPCC_FLAGS + ['-o', str(LIB_PATH), str(_SRC / 'engine.hip')] + LINK_FLAGS
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=str(_SRC))

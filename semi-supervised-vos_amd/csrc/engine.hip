@@ -18,6 +18,7 @@
 #include "prop_bf16.h"
 #include "prop_bf16_v5.h"
 #include "prop_bf16_v6.h"
+#include "pointwise.h"
 #include "encoder_ops.h"
 
 using namespace vosprop;
@@ -522,6 +523,23 @@ int vosprop_bias_act(void* y, const void* bias, const void* residual, long long 
     } else return VOSPROP_E_INVALID;
 #undef VOSPROP_BA
     return hipGetLastError() == hipSuccess ? VOSPROP_OK : VOSPROP_E_HIP;
+}
+
+int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, const void* residual, void* y, long long pixels,
+                           int cin, int cout, int relu, int dtype, void* stream) {
+    hipDataType dt;
+    switch (dtype) {
+        case VOSPROP_DT_BF16: dt = HIP_R_16BF; break;
+        case VOSPROP_DT_F16: dt = HIP_R_16F; break;
+        case VOSPROP_DT_F32: dt = HIP_R_32F; break;
+        default: return VOSPROP_E_INVALID;
+    }
+    switch (pointwise_conv(x, weight, bias, residual, y, pixels, cin, cout, relu, dt, dtype, (hipStream_t)stream)) {
+        case 0: return VOSPROP_OK;
+        case 1: return VOSPROP_E_INVALID;
+        case 3: return VOSPROP_E_UNSUPPORTED;
+        default: return VOSPROP_E_HIP;
+    }
 }
 
 /* test hook (no GPU needed): segment table for TT target tiles x NT reference tiles; rows of out = (workgroup, tt, r_lo, n_steps) */

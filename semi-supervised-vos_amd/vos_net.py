@@ -13,6 +13,7 @@ Differences, on purpose:
     hand-written HIP part of this project.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -45,6 +46,44 @@ def bias_act_(y, bias, residual=None, relu=True):
 
 def _conv_nobias(x, conv):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+_POINTWISE_GEMM = os.environ.get('VOSPROP_POINTWISE', '1') != '0'     # dev switch: 0 = every convolution through MIOpen
+
+
+def _is_pointwise(conv):
+    return (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+            and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0)
+
+
+def conv_bias_act(x, conv, bias, residual=None, relu=True):
+    """act(conv(x) + bias (+ residual)) for one folded convolution.  A pointwise convolution over a channels-last GPU tensor
+    is one GEMM with the epilogue inside (vosprop_pointwise_conv, csrc/pointwise.h: the output is written once); anything else
+    is the library convolution followed by one pass of bias_act_."""
+    if (_POINTWISE_GEMM and x.is_cuda and x.dtype in _DT and x.dim() == 4 and _is_pointwise(conv)
+            and x.is_contiguous(memory_format=torch.channels_last) and conv.weight.dtype == x.dtype
+            and (bias is None or bias.dtype == x.dtype)
+            and (residual is None or (residual.dtype == x.dtype and residual.is_contiguous(memory_format=torch.channels_last)))):
+        from . import _native
+        n, _, h, w = x.shape
+        y = torch.empty((n, conv.out_channels, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        assert residual is None or residual.shape == y.shape
+        rc = _native.lib().vosprop_pointwise_conv(
+            ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(conv.weight.data_ptr()),
+            ctypes.c_void_p(bias.data_ptr()) if bias is not None else None,
+            ctypes.c_void_p(residual.data_ptr()) if residual is not None else None,
+            ctypes.c_void_p(y.data_ptr()), n * h * w, conv.in_channels, conv.out_channels, int(bool(relu)), _DT[x.dtype],
+            ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+        if rc == 0:
+            return y
+        if rc != -4:          # VOSPROP_E_UNSUPPORTED (no library kernel for this shape) falls through to the convolution
+            raise _native.VospropError(f'vosprop_pointwise_conv failed ({rc})')
+    y = _conv_nobias(x, conv)
+    if bias is None and residual is None and not relu:
+        return y
+    if bias is None:
+        bias = torch.zeros(conv.out_channels, dtype=y.dtype, device=y.device)
+    return bias_act_(y, bias, residual, relu)
 
 # (block kind, blocks per stage) - reference resnet.py:159-216
 _ARCH = {
@@ -91,12 +130,12 @@ class ResidualUnit(nn.Module):
         if self.downsample is None:
             skip, b_out = x, (self.conv3 if self.kind != 'basic' else self.conv2).bias
         else:
-            skip, b_out = _conv_nobias(x, self.downsample[0]), self.bias_out
-        y = bias_act_(_conv_nobias(x, self.conv1), self.conv1.bias)
+            skip, b_out = conv_bias_act(x, self.downsample[0], None, None, relu=False), self.bias_out
+        y = conv_bias_act(x, self.conv1, self.conv1.bias)
         if self.kind == 'basic':
-            return bias_act_(_conv_nobias(y, self.conv2), b_out, skip)
-        y = bias_act_(_conv_nobias(y, self.conv2), self.conv2.bias)
-        return bias_act_(_conv_nobias(y, self.conv3), b_out, skip)
+            return conv_bias_act(y, self.conv2, b_out, skip)
+        y = conv_bias_act(y, self.conv2, self.conv2.bias)
+        return conv_bias_act(y, self.conv3, b_out, skip)
 
     def forward(self, x):
         if self.fused:
@@ -158,7 +197,7 @@ class VOSNet(nn.Module):
             for stage in list(bb)[4:]:
                 x = stage(x)
             if self.model != 'resnet18':
-                x = bias_act_(_conv_nobias(x, self.adjust_dim), self.adjust_dim.bias, None, relu=False)
+                x = conv_bias_act(x, self.adjust_dim, self.adjust_dim.bias, None, relu=False)
             return x
         x = self.backbone(x)
         if self.model != 'resnet18':
