@@ -147,6 +147,13 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
 int vosprop_bias_act(void* y, const void* bias, const void* residual, long long pixels, int channels, int relu, int dtype,
                      void* stream);
 
+/* Stem epilogue, context-free: y[n, oh, ow, c] = relu(max_{3x3 window, stride 2, pad 1} x[n, ., ., c] + bias[c]) - the BatchNorm
+ * shift, ReLU and 3x3/2 max-pool after the 7x7 stem convolution (src/model/backbone/resnet.py:104-107) in one pass over the
+ * channels-last activation x (n, h, w, channels); y is (n, (h-1)/2+1, (w-1)/2+1, channels).  Bit-identical to bias + ReLU (rounded
+ * to `dtype`) followed by the pool, because all three are monotone.  channels % 8 == 0; x, bias, y share `dtype`. */
+int vosprop_bias_relu_maxpool(const void* x, const void* bias, void* y, int n, int h, int w, int channels, int dtype,
+                              void* stream);
+
 /* Pointwise (1x1, stride 1, no padding) convolution with its epilogue, context-free:
  *     y[p, co] = act( sum_ci x[p, ci] * weight[co, ci] + bias[co] (+ residual[p, co]) )
  * over channels-last tensors viewed as (pixels, channels) - conv1 / conv3 / downsample[0] of the reference's bottleneck units and

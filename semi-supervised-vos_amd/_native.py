@@ -50,6 +50,8 @@ SYMBOLS = {
     'vosprop_timing_begin': (ctypes.c_int, [_vp]),
     'vosprop_timing_read': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     'vosprop_bias_act': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
+    'vosprop_bias_relu_maxpool': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, _vp]),
     'vosprop_pointwise_conv': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, _vp]),
     'vosprop_frame_index': (ctypes.c_int, [_vp]),

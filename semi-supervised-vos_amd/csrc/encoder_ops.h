@@ -65,4 +65,49 @@ __global__ __launch_bounds__(256) void bias_act_f32_kernel(float* __restrict__ y
     }
 }
 
+// Stem epilogue: y[n, oh, ow, c] = relu(max over the 3x3 / stride 2 / pad 1 window of x[n, ., ., c] + bias[c]) - the bias (folded
+// BatchNorm), ReLU and max-pool that follow the 7x7 stem convolution (reference src/model/backbone/resnet.py:104-107, children
+// 1-3 of the truncated ResNet) in one pass: the largest activation of the network (64 x H/2 x W/2) is read once and a quarter of
+// it written, instead of read + written by the bias / ReLU pass and read again by the pooling kernel.  Bias add, rounding and
+// ReLU are monotone, so taking the max first gives the same bits as pooling the rounded activations.  G elements (16 B) per
+// lane, C % G == 0; HBM-bound.
+template <typename T, typename V, int G>
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const T* __restrict__ x, const T* __restrict__ bias,
+                                                                T* __restrict__ y, int N, int H, int W, int C, int OH, int OW) {
+    const int cg = C / G;
+    const long long total = (long long)N * OH * OW * cg;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % cg) * G;
+        long long p = i / cg;
+        const int ow = (int)(p % OW);
+        p /= OW;
+        const int oh = (int)(p % OH), n = (int)(p / OH);
+        float m[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) m[k] = -3.0e38f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int ih = oh * 2 + dy;
+            if (ih < 0 || ih >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int iw = ow * 2 + dx;
+                if (iw < 0 || iw >= W) continue;
+                const V v = *(const V*)(x + (((long long)n * H + ih) * W + iw) * C + c);
+#pragma unroll
+                for (int k = 0; k < G; ++k) m[k] = fmaxf(m[k], (float)v[k]);
+            }
+        }
+        const V b = *(const V*)(bias + c);
+        V o;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const T r = (T)(m[k] + (float)b[k]);      // round as the separate bias pass does, then ReLU
+            o[k] = (float)r > 0.0f ? r : (T)0.0f;
+        }
+        *(V*)(y + i * G) = o;
+    }
+}
+
 }  // namespace vosprop

@@ -525,6 +525,31 @@ int vosprop_bias_act(void* y, const void* bias, const void* residual, long long 
     return hipGetLastError() == hipSuccess ? VOSPROP_OK : VOSPROP_E_HIP;
 }
 
+int vosprop_bias_relu_maxpool(const void* x, const void* bias, void* y, int n, int h, int w, int channels, int dtype,
+                              void* stream) {
+    if (!x || !bias || !y || n < 0 || h <= 0 || w <= 0 || channels < 8 || channels % 8) return VOSPROP_E_INVALID;
+    if (n == 0) return VOSPROP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int oh = (h - 1) / 2 + 1, ow = (w - 1) / 2 + 1;
+    const int G = dtype == VOSPROP_DT_F32 ? 4 : 8;
+    const long long total = (long long)n * oh * ow * (channels / G);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const dim3 grid((unsigned)blocks), block(256);
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    if (dtype == VOSPROP_DT_BF16)
+        hipLaunchKernelGGL((bias_relu_maxpool_kernel<bf16_t, Vec8<bf16_t>::type, 8>), grid, block, 0, s, (const bf16_t*)x,
+                           (const bf16_t*)bias, (bf16_t*)y, n, h, w, channels, oh, ow);
+    else if (dtype == VOSPROP_DT_F16)
+        hipLaunchKernelGGL((bias_relu_maxpool_kernel<_Float16, Vec8<_Float16>::type, 8>), grid, block, 0, s, (const _Float16*)x,
+                           (const _Float16*)bias, (_Float16*)y, n, h, w, channels, oh, ow);
+    else if (dtype == VOSPROP_DT_F32)
+        hipLaunchKernelGGL((bias_relu_maxpool_kernel<float, f32x4v, 4>), grid, block, 0, s, (const float*)x, (const float*)bias,
+                           (float*)y, n, h, w, channels, oh, ow);
+    else return VOSPROP_E_INVALID;
+    return hipGetLastError() == hipSuccess ? VOSPROP_OK : VOSPROP_E_HIP;
+}
+
 int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, const void* residual, void* y, long long pixels,
                            int cin, int cout, int relu, int dtype, void* stream) {
     hipDataType dt;

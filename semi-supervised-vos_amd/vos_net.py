@@ -44,6 +44,25 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y.relu_() if relu else y
 
 
+def bias_relu_maxpool(y, bias, pool):
+    """pool(relu(y + bias[c])) for the stem (3x3 / stride 2 / pad 1 max-pool): on the GPU one pass of vosprop_bias_relu_maxpool
+    (csrc/encoder_ops.h) - the network's largest activation is read once; anywhere else the separate steps.  Same bits."""
+    if (y.is_cuda and y.dtype in _DT and y.dim() == 4 and y.shape[1] % 8 == 0 and bias.dtype == y.dtype
+            and y.is_contiguous(memory_format=torch.channels_last) and isinstance(pool, nn.MaxPool2d)
+            and (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False)):
+        from . import _native
+        n, c, h, w = y.shape
+        out = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=y.dtype, device=y.device,
+                          memory_format=torch.channels_last)
+        rc = _native.lib().vosprop_bias_relu_maxpool(
+            ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(bias.data_ptr()), ctypes.c_void_p(out.data_ptr()), n, h, w, c,
+            _DT[y.dtype], ctypes.c_void_p(torch.cuda.current_stream(y.device).cuda_stream))
+        if rc != 0:
+            raise _native.VospropError(f'vosprop_bias_relu_maxpool failed ({rc})')
+        return out
+    return pool(bias_act_(y, bias))
+
+
 def _conv_nobias(x, conv):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
@@ -193,7 +212,7 @@ class VOSNet(nn.Module):
     def forward(self, x):
         if self.fused:
             bb = self.backbone
-            x = bb[3](bias_act_(_conv_nobias(x, bb[0]), bb[0].bias))      # stem conv + folded BN + ReLU, max-pool
+            x = bias_relu_maxpool(_conv_nobias(x, bb[0]), bb[0].bias, bb[3])      # stem conv; folded BN + ReLU + max-pool
             for stage in list(bb)[4:]:
                 x = stage(x)
             if self.model != 'resnet18':

@@ -207,3 +207,21 @@ def test_pointwise_algorithm_inherited_across_pixel_counts():
             got = vn.conv_bias_act(x, conv, conv.bias.detach(), r, True)
         tol = 2.0 ** -8 * (float(want.abs().max()) + 1.0) * 2
         assert float((got.float() - want).abs().max()) <= tol, (n, h, w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+def test_stem_bias_relu_maxpool_kernel(dtype):
+    """vosprop_bias_relu_maxpool against the three steps it replaces (bias add rounded to the tensor type, ReLU, 3x3/2 max-pool):
+    bit-identical, odd and even sizes, image borders included."""
+    vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
+    torch.manual_seed(4)
+    dev = torch.device('cuda', 0)
+    pool = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    for (n, c, h, w) in [(2, 64, 17, 23), (1, 8, 1, 1), (1, 16, 2, 5), (3, 64, 48, 80), (1, 64, 240, 427)]:
+        y = torch.randn(n, c, h, w, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(c, device=dev).to(dtype)
+        want = pool((y.float() + b.float().view(1, -1, 1, 1)).to(dtype).relu())
+        got = vn.bias_relu_maxpool(y, b, pool)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got, want), (n, c, h, w, float((got.float() - want.float()).abs().max()))
