@@ -56,7 +56,15 @@ inline bool pw_capturing(hipStream_t s) {
 }
 
 constexpr size_t kPwWorkspace = 32u << 20;
-constexpr int kPwCandidates = 64;
+constexpr int kPwCandidatesDefault = 48;
+inline int pw_candidates() {      // VOSPROP_PW_CANDIDATES: how many of the library's ranked algorithms the first call of a layer kind times
+    static const int n = [] {
+        const char* e = getenv("VOSPROP_PW_CANDIDATES");
+        const int v = e ? atoi(e) : kPwCandidatesDefault;
+        return v < 1 ? 1 : (v > 1024 ? 1024 : v);
+    }();
+    return n;
+}
 
 // returns 0 on success, 1 = invalid argument, 2 = library / HIP failure, 3 = no algorithm for this shape
 inline int pointwise_conv(const void* x, const void* w, const void* bias, const void* residual, void* y, long long pixels,
@@ -123,9 +131,10 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
         if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return 2;
         const uint64_t max_ws = D.ws_bytes;
         hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws));
-        std::vector<hipblasLtMatmulHeuristicResult_t> res(kPwCandidates);
+        const int want = pw_candidates();
+        std::vector<hipblasLtMatmulHeuristicResult_t> res(want);
         int got = 0;
-        const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(D.handle, P.desc, P.lw, P.lx, P.ly, P.ly, pref, kPwCandidates,
+        const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(D.handle, P.desc, P.lw, P.lx, P.ly, P.ly, pref, want,
                                                                    res.data(), &got);
         hipblasLtMatmulPreferenceDestroy(pref);
         if (hs != HIPBLAS_STATUS_SUCCESS || got <= 0) return 3;
@@ -140,16 +149,25 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
             hipEvent_t e0, e1;
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 2;
             float best_ms = 1e30f;
+            // one timed launch per candidate after a warm one (which also loads its code object); only candidates within 15 %
+            // of the best so far get a 3-launch measurement - the search costs ~2 launches per candidate instead of 4
+            auto timed = [&](int i, int reps, float* ms) {
+                (void)hipEventRecord(e0, s);
+                bool fine = true;
+                for (int r = 0; r < reps && fine; ++r) fine = run(res[i].algo, res[i].workspaceSize) == HIPBLAS_STATUS_SUCCESS;
+                (void)hipEventRecord(e1, s);
+                if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); fine = false; }
+                if (!fine || hipEventElapsedTime(ms, e0, e1) != hipSuccess) return false;
+                *ms /= (float)reps;
+                return true;
+            };
             for (int i = 0; i < got; ++i) {
                 if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > D.ws_bytes) continue;
                 if (run(res[i].algo, res[i].workspaceSize) != HIPBLAS_STATUS_SUCCESS) continue;   // warm
-                (void)hipEventRecord(e0, s);
-                bool fine = true;
-                for (int r = 0; r < 3 && fine; ++r) fine = run(res[i].algo, res[i].workspaceSize) == HIPBLAS_STATUS_SUCCESS;
-                (void)hipEventRecord(e1, s);
-                if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); fine = false; }
                 float ms = 0.f;
-                if (fine && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = i; }
+                if (!timed(i, 1, &ms) || ms > 1.15f * best_ms) continue;
+                if (!timed(i, 3, &ms)) continue;
+                if (ms < best_ms) { best_ms = ms; best = i; }
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
@@ -161,7 +179,7 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
             }
             if (getenv("VOSPROP_PW_VERBOSE"))
                 fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d (bias %d relu %d residual %d): %d candidates, #%d wins, %.1f us\n",
-                        pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, best, best_ms / 3 * 1e3f);
+                        pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, best, best_ms * 1e3f);
         }
         if (best < 0) return 3;
         P.algo = res[best].algo;
