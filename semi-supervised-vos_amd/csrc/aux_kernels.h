@@ -131,7 +131,38 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
     float acc[kMaxClasses];
 #pragma unroll
     for (int k = 0; k < kMaxClasses; ++k) acc[k] = 0.0f;
-    for (int u = u0 + g; u < u1; u += 4) {
+    // The kernel is latency-bound (101 workgroups, a few KB each): the first kPre partials of a lane are fetched with all their
+    // loads in flight at once - slot ids, then every value - instead of one dependent round trip per partial (a tile has ~10
+    // partials with the lockstep map, so the loop below normally does not run).
+    constexpr int kPre = 3;
+    int sl[kPre];
+#pragma unroll
+    for (int q = 0; q < kPre; ++q) {
+        const int u = u0 + g + 4 * q;
+        sl[q] = u < u1 ? plist[u] : -1;
+    }
+    float pm[kPre], pl[kPre], pa[kPre][kMaxClasses];
+#pragma unroll
+    for (int q = 0; q < kPre; ++q) {
+        const float* pu = part + (size_t)(sl[q] < 0 ? 0 : sl[q]) * ustride + tcol;
+        const bool on = sl[q] >= 0;
+        pm[q] = on ? pu[0] : -3.0e38f;
+        pl[q] = on ? pu[kBT] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < kMaxClasses; ++k) pa[q][k] = (on && k < d) ? pu[(size_t)(2 + k) * kBT] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < kPre; ++q) {
+        if (sl[q] < 0) continue;
+        const float Mn = fmaxf(M, pm[q]);
+        const float so = __builtin_amdgcn_exp2f((M - Mn) * c), sn = __builtin_amdgcn_exp2f((pm[q] - Mn) * c);
+        Lsum = Lsum * so + pl[q] * sn;
+#pragma unroll
+        for (int k = 0; k < kMaxClasses; ++k)
+            if (k < d) acc[k] = acc[k] * so + pa[q][k] * sn;
+        M = Mn;
+    }
+    for (int u = u0 + g + 4 * kPre; u < u1; u += 4) {
         const float* pu = part + (size_t)plist[u] * ustride + tcol;
         const float m = pu[0];
         const float Mn = fmaxf(M, m);
