@@ -45,6 +45,7 @@ def main():
     ap.add_argument('--model', default='resnet50')
     ap.add_argument('--io-workers', type=int, nargs='+', default=[1, 8])
     ap.add_argument('--png-workers', type=int, nargs='+', default=[2])
+    ap.add_argument('--extra', default='', help='further flags for main.py inference, e.g. "--encoder-batch 64 --miopen-find"')
     ap.add_argument('--profile', action='store_true', help='re-run the last configuration under cProfile and print the top functions')
     args = ap.parse_args()
     import importlib
@@ -61,14 +62,14 @@ def main():
                 t0 = time.perf_counter()
                 out = subprocess.run([sys.executable, 'main.py', 'inference', '-d', str(td / 'data'), '-r', str(td / 'ckpt.pth.tar'),
                                       '-m', args.model, '-s', str(td / f'out_{io}_{png}'), '--io-workers', str(io),
-                                      '--png-workers', str(png)], cwd=ROOT, capture_output=True, text=True, timeout=1200)
+                                      '--png-workers', str(png)] + args.extra.split(), cwd=ROOT, capture_output=True, text=True, timeout=1200)
                 wall = time.perf_counter() - t0
                 if out.returncode != 0:
                     print(json.dumps({'io_workers': io, 'png_workers': png, 'error': out.stderr[-400:]}))
                     continue
                 st = json.loads([l for l in out.stdout.splitlines() if l.startswith('{"vosprop_stats"')][0])['vosprop_stats']
                 n_png = len(list((td / f'out_{io}_{png}').glob('*/*.png')))
-                print(json.dumps({'io_workers': io, 'png_workers': png, 'frames': st['frames'], 'loop_seconds': round(st['seconds'], 3),
+                print(json.dumps({'io_workers': io, 'png_workers': png, 'extra': args.extra, 'frames': st['frames'], 'loop_seconds': round(st['seconds'], 3),
                                   'loop_frames_per_s': round(st['frames'] / st['seconds'], 1), 'process_wall_s': round(wall, 2),
                                   'pngs_written': n_png}), flush=True)
         if args.profile:

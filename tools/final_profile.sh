@@ -14,9 +14,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/encprof -- 
 rm -rf $O/encprof
 echo "encoder profile done"
 cd $R
-timeout -k 10 300 python tools/cli_bench.py --videos 16 --frames 128 --io-workers 4 8 --png-workers 2 4 > $O/cli_end_to_end.txt 2>&1 || echo "cli bench failed"
+timeout -k 10 300 python tools/cli_bench.py --videos 16 --frames 128 --io-workers 8 8 8 --png-workers 2 > $O/cli_end_to_end.txt 2>&1 || echo "cli bench failed"
+timeout -k 10 300 python tools/cli_bench.py --videos 16 --frames 128 --io-workers 8 --png-workers 2 --extra "--encoder-batch 64" >> $O/cli_end_to_end.txt 2>&1 || echo "cli bench failed"
+timeout -k 10 300 python tools/cli_bench.py --videos 48 --frames 128 --io-workers 8 --png-workers 2 >> $O/cli_end_to_end.txt 2>&1 || echo "cli bench failed"
 echo "cli done"
-for wl in davis480p_r50_top20_ref5 ytvos720p_r50_dense; do
+for wl in davis480p_r50_top20_ref5 ytvos720p_r50_dense pair240p_r18; do
   timeout -k 10 300 python bench.py --workload $wl --no-cpu-baseline > $O/bench_$wl.json 2> $O/bench_$wl.err || echo "$wl failed"
 done
 timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err || echo "bench failed"
