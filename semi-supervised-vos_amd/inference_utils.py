@@ -25,15 +25,18 @@ def _read_annotation(path):
 
 def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None):
     """Encoder look-ahead for every strategy: yields ([features (1,C,H_d,W_d) per branch], video_name) in loader order, but
-    runs each encoder on up to `batch` consecutive frames of one video at a time - the features do not depend on the
-    propagated labels (only the labels are sequential), and the encoder is ~3.5x cheaper per frame at batch 16 than at
-    batch 1 on MI355X.  `models`: one encoder per branch.  A loader item carries one tensor (every branch sees it) or one
+    runs each encoder on `batch` consecutive frames at a time - the features do not depend on the propagated labels (only the
+    labels are sequential) nor on the video, and the encoder is ~3.5x cheaper per frame at batch 16 than at batch 1 on
+    MI355X.  A batch runs across video boundaries and, on the GPU, a short one (end of the data, change of frame size) is padded
+    to `batch` frames: every new batch size costs MIOpen look-ups, a GEMM plan and a graph capture - far more than encoding a
+    few frames too many - so the encoder only ever sees ONE shape per frame size.  `models`: one encoder per branch.  A loader item carries one tensor (every branch sees it) or one
     tensor per branch (the flip / 2-scale datasets).  `resize(H, W) -> (h, w)`: nearest pre-scaling of the input, the
     3-scale strategy's (reference inference_utils.py:523-526)."""
     nb = len(models)
     pend = [[] for _ in range(nb)]
     names = []
     copy_stream = [torch.cuda.Stream(device)]
+    pad = torch.device(device).type == 'cuda' and batch > 1
 
     def flush():
         feats = []
@@ -44,9 +47,12 @@ def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None):
             first = pend[b][0]
             compute = torch.cuda.current_stream(device)
             with torch.cuda.stream(copy_stream[0]):
-                x = torch.empty((len(pend[b]),) + tuple(first.shape[1:]), dtype=first.dtype, device=device)
+                n = len(pend[b])
+                x = torch.empty((batch if pad else n,) + tuple(first.shape[1:]), dtype=first.dtype, device=device)
                 for i, t in enumerate(pend[b]):
                     x[i:i + 1].copy_(t, non_blocking=True)
+                if x.shape[0] > n:
+                    x[n:].zero_()       # padding frames: encoded and dropped (samples are independent: BatchNorm is folded)
                 copied = torch.cuda.Event()
                 copied.record(copy_stream[0])
             compute.wait_event(copied)
@@ -75,8 +81,7 @@ def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None):
         ins = list(input) if isinstance(input, (list, tuple)) else [input] * nb
         if len(ins) != nb:
             raise ValueError(f'loader item carries {len(ins)} inputs, the strategy has {nb} branches')
-        if names and (name != names[-1] or len(names) == batch or any(ins[b].shape != pend[b][-1].shape
-                                                                       for b in range(nb))):
+        if names and (len(names) == batch or any(ins[b].shape != pend[b][-1].shape for b in range(nb))):
             yield from flush()
         for b in range(nb):
             pend[b].append(ins[b])

@@ -16,7 +16,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def make_dataset(root, videos, frames, H, W):
+def make_dataset(root, videos, frames, H, W, vary=False):
     from PIL import Image
     yy, xx = np.mgrid[0:H, 0:W]
     for v in range(videos):
@@ -24,7 +24,7 @@ def make_dataset(root, videos, frames, H, W):
         (root / 'JPEGImages' / '480p' / f'v{v:02d}').mkdir(parents=True)
         (root / 'Annotations' / '480p' / f'v{v:02d}').mkdir(parents=True)
         base = rs.randint(0, 255, (H // 16, W // 16, 3)).astype(np.float32)
-        for i in range(frames):
+        for i in range(frames - ((v * 7) % 32 if vary else 0)):     # vary: DAVIS-like, every video its own length
             base = np.clip(base + rs.randn(*base.shape) * 5, 0, 255)
             img = Image.fromarray(base.astype(np.uint8)).resize((W, H), Image.BILINEAR)
             img.save(root / 'JPEGImages' / '480p' / f'v{v:02d}' / f'{i:05d}.jpg', quality=90)
@@ -45,6 +45,7 @@ def main():
     ap.add_argument('--model', default='resnet50')
     ap.add_argument('--io-workers', type=int, nargs='+', default=[1, 8])
     ap.add_argument('--png-workers', type=int, nargs='+', default=[2])
+    ap.add_argument('--vary', action='store_true', help='videos of different lengths (frames - (7 v mod 32))')
     ap.add_argument('--extra', default='', help='further flags for main.py inference, e.g. "--encoder-batch 64 --miopen-find"')
     ap.add_argument('--profile', action='store_true', help='re-run the last configuration under cProfile and print the top functions')
     args = ap.parse_args()
@@ -54,7 +55,7 @@ def main():
     vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
     with tempfile.TemporaryDirectory() as td:
         td = Path(td)
-        make_dataset(td / 'data', args.videos, args.frames, *args.size)
+        make_dataset(td / 'data', args.videos, args.frames, *args.size, vary=args.vary)
         torch.manual_seed(0)
         torch.save({'state_dict': vn.VOSNet(args.model).state_dict()}, td / 'ckpt.pth.tar')
         for io in args.io_workers:
