@@ -24,17 +24,8 @@ struct PwPlan {
     hipblasLtMatrixLayout_t lw = nullptr, lx = nullptr, ly = nullptr;
     hipblasLtMatmulAlgo_t algo;
     size_t ws = 0;
-    bool tuned = false;      // algo was timed (here, or inherited from a timed plan of the same layer kind)
-    bool inherited = false;
+    bool tuned = false;      // algo was timed on this exact problem
     bool ok = false;
-};
-
-// the winner of the last timing of a layer kind (cin, cout, dtype, epilogue, residual): other pixel counts of the same kind
-// (the tail batch of every video is a new one) take it over instead of timing 64 candidates again
-struct PwTuned {
-    hipblasLtMatmulAlgo_t algo;
-    size_t ws = 0;
-    long long pixels = 0;
 };
 
 struct PwDevice {
@@ -43,7 +34,6 @@ struct PwDevice {
     size_t ws_bytes = 0;
     // (pixels, cin, cout, dtype, epilogue, residual) -> plan
     std::map<std::tuple<long long, int, int, int, int, int>, PwPlan> plans;
-    std::map<std::tuple<int, int, int, int, int>, PwTuned> tuned;
 };
 
 inline std::mutex& pw_mutex() { static std::mutex m; return m; }
@@ -118,14 +108,6 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
                                ws ? D.workspace : nullptr, ws, s);
     };
 
-    PwTuned& T = D.tuned[std::make_tuple(cin, cout, dtype_key, ep_key, residual ? 1 : 0)];
-    if (!P.ok && T.pixels > 0 && pixels <= 2 * T.pixels && T.ws <= D.ws_bytes) {
-        P.algo = T.algo;
-        P.ws = T.ws;
-        P.ok = P.tuned = P.inherited = true;
-        if (run(P.algo, P.ws) == HIPBLAS_STATUS_SUCCESS) return 0;
-        P.ok = P.tuned = P.inherited = false;      // not valid for this size after all: ask the library
-    }
     if (!P.ok || (!P.tuned && !capturing && residual != y)) {
         hipblasLtMatmulPreference_t pref = nullptr;
         if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return 2;
@@ -172,11 +154,6 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             P.tuned = best >= 0;
-            if (best >= 0 && pixels >= T.pixels) {
-                T.algo = res[best].algo;
-                T.ws = res[best].workspaceSize;
-                T.pixels = pixels;
-            }
             if (getenv("VOSPROP_PW_VERBOSE"))
                 fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d (bias %d relu %d residual %d): %d candidates, #%d wins, %.1f us\n",
                         pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, best, best_ms * 1e3f);

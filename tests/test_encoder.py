@@ -191,15 +191,15 @@ def test_pointwise_gemm_is_the_path_taken_and_matches_the_convolution_path():
 
 
 @pytest.mark.gpu
-def test_pointwise_algorithm_inherited_across_pixel_counts():
-    """A layer kind is timed once; other pixel counts of it (every video's tail batch) take the winner over.  Results must not
-    depend on that: odd and tiny pixel counts after a large one, each against the f32 reference."""
+def test_pointwise_conv_over_many_pixel_counts():
+    """One layer kind at large, odd and tiny pixel counts in turn (each gets its own plan: a library algorithm is only valid for
+    the problem it was queried for), each against the f32 reference."""
     vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
     torch.manual_seed(5)
     dev = torch.device('cuda', 0)
     dt = torch.bfloat16
     conv = torch.nn.Conv2d(256, 1024, 1, bias=True).to(dev).to(dt).to(memory_format=torch.channels_last)
-    for (n, h, w) in [(8, 60, 107), (1, 7, 5), (3, 1, 1), (4, 29, 53), (9, 60, 107), (1, 1, 1)]:
+    for (n, h, w) in [(16, 60, 107), (1, 7, 5), (3, 1, 1), (4, 29, 53), (17, 60, 107), (1, 1, 1)]:
         x = torch.randn(n, 256, h, w, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
         r = torch.randn(n, 1024, h, w, device=dev).to(dt).contiguous(memory_format=torch.channels_last)
         want = (torch.nn.functional.conv2d(x.float(), conv.weight.detach().float(), conv.bias.detach().float()) + r.float()).relu()
