@@ -235,13 +235,14 @@ def main():
 
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them, in
     # their own passes), so the line carries the committed measurement for this workload (tools/traffic_pmc.sh) or null
-    traffic, traffic_src = None, None
+    traffic, traffic_src, pmc = None, None, {}
     tj = Path(__file__).resolve().parent / 'profiles' / 'r01_prop_kernel_traffic.json'
     if args.workload == 'davis480p_r50_dense' and tj.exists():
         try:
             t = json.loads(tj.read_text())
             traffic = float(t['traffic_bytes_per_launch'])
             traffic_src = 'profiles/r01_prop_kernel_traffic.json: ' + t['how']
+            pmc = {k: t[k] for k in ('mfma_busy_frac', 'l2_hit_rate', 'hbm_gb_per_s', 'counters_source') if k in t}
         except Exception:
             traffic = None
     if rank == 0:
@@ -259,7 +260,7 @@ def main():
                          'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us,
                          'kernel_launches_timed': timed_launches, 'kernel_us_back_to_back': b2b_us, 'flops_per_launch': st['flops'],
-                         'algorithmic_bytes_per_launch': st['bytes'], 'workgroups': st['workgroups']},
+                         'algorithmic_bytes_per_launch': st['bytes'], 'workgroups': st['workgroups'], 'pmc': pmc},
         }
         if world == 1 and not args.no_cpu_baseline:
             T0 = len(keep_feats)
