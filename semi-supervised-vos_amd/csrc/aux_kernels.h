@@ -115,10 +115,23 @@ __device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t*
 // them from the same WorkMap the propagation kernel uses.
 // grid = ceil(HW/64), block = 256 = 64 target pixels x 4 partial lanes (each lane folds every 4th partial with its own
 // running max; the 4 lanes are merged through LDS), then the block's two 32-pixel label tiles are packed (256 chunks).
+// Optional tail of combine_kernel: the nearest up-sampling of the block's 64 class indices into the full-size mask (reference
+// inference_utils.py:74-75; argmax and nearest interpolation commute) - saves the separate up-sampling launch and its dispatch gap.
+// y0 / x0: first output row / column whose ATen nearest source index (min(floor(dst * scale), in - 1), scale = (float)in / out
+// computed on the host as ATen does) is >= i, for i = 0..Hd / 0..Wd; built on the host with the same float arithmetic.
+struct UpArgs {
+    uint8_t* mask;     // (H, W) or nullptr
+    const int* y0;     // Hd + 1
+    const int* x0;     // Wd + 1
+    int H, W, Hd, Wd;
+    float sx;
+};
+
 __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ part, const int* __restrict__ plist_off,
                                                       const int* __restrict__ plist, int d, int HW, float c,
                                                       float* __restrict__ pred, uint8_t* __restrict__ cls,
-                                                      bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, int prob) {
+                                                      bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, int prob,
+                                                      const UpArgs up) {
     __shared__ float red[4][kMaxClasses + 2][64];
     __shared__ float outv[kMaxClasses][64];
     __shared__ uint8_t clsv[64];
@@ -200,8 +213,23 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
         clsv[col] = (uint8_t)best;
         if (t < HW) cls[t] = (uint8_t)best;
     }
-    if (!lab_hi) return;
+    if (!lab_hi && !up.mask) return;
     __syncthreads();
+    if (up.mask) {
+        // the block's low-res pixels [t0, t1) lie in at most two rows of the map; each row segment owns a rectangle of the mask
+        const int t0 = blockIdx.x * 64, t1 = t0 + 64 < HW ? t0 + 64 : HW;
+        for (int ry = t0 / up.Wd; ry * up.Wd < t1; ++ry) {
+            const int ra = t0 - ry * up.Wd > 0 ? t0 - ry * up.Wd : 0, rb = t1 - ry * up.Wd < up.Wd ? t1 - ry * up.Wd : up.Wd;
+            const int xa = up.x0[ra], nx = up.x0[rb] - xa, ya = up.y0[ry], ny = up.y0[ry + 1] - ya;
+            for (int i = tid; i < nx * ny; i += 256) {
+                const int yy = i / nx, x = xa + i - yy * nx;
+                int ix = (int)floorf((float)x * up.sx);
+                ix = ix < up.Wd - 1 ? ix : up.Wd - 1;
+                up.mask[(size_t)(ya + yy) * up.W + x] = clsv[ry * up.Wd + ix - t0];
+            }
+        }
+    }
+    if (!lab_hi) return;
     pack_block_labels(outv, clsv, d, HW, prob, lab_hi, lab_lo);
 }
 
@@ -347,11 +375,12 @@ __global__ __launch_bounds__(256) void topk_combine_kernel(const TopkCombineArgs
 // Nearest up-sampling of the class map (reference inference_utils.py:74-75; argmax and nearest
 // interpolation commute, so the index map is up-sampled instead of the d-channel prediction).
 // ATen's nearest source index: min(floor(dst * (float)in/out), in-1).
-__global__ void upsample_kernel(const uint8_t* __restrict__ cls, int Hd, int Wd, uint8_t* __restrict__ mask, int H, int W) {
+// sy, sx = (float)in / (float)out computed on the host, as ATen does (device f32 division is not correctly rounded).
+__global__ void upsample_kernel(const uint8_t* __restrict__ cls, int Hd, int Wd, uint8_t* __restrict__ mask, int H, int W,
+                                float sy, float sx) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
-    const float sy = (float)Hd / (float)H, sx = (float)Wd / (float)W;
     int iy = (int)floorf((float)y * sy), ix = (int)floorf((float)x * sx);
     iy = iy < Hd - 1 ? iy : Hd - 1;
     ix = ix < Wd - 1 ? ix : Wd - 1;

@@ -84,6 +84,12 @@ struct vosprop_ctx {
     bool in_video = false;
     int frame_idx = 0;
     int d = 0, H = 0, W = 0;
+    // nearest up-sampling fused into combine_kernel (dense path): inverse index tables for the current output size
+    int* up_tab = nullptr;         // device: y0[feat_h + 1], x0[feat_w + 1]
+    std::vector<int> up_host;
+    int up_H = 0, up_W = 0;
+    float up_sy = 0.f, up_sx = 0.f;
+    uint8_t* fuse_mask = nullptr;  // set by vosprop_step around propagate(): the mask combine_kernel should write
     LastProp last;
     std::vector<Plan> plans;   // cache keyed by NT (n_ref * tiles)
     vosprop_stats stats;
@@ -424,8 +430,17 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         ca.k = topk; ca.d = d; ca.HW = ctx->HW; ca.HWp = ctx->HWp; ca.c = a.c;
         hipLaunchKernelGGL(topk_combine_kernel, cgrid, dim3(256), 0, s, ca, pred, cls, new_lab_hi, new_lab_lo);
     } else {
+        UpArgs up;
+        memset(&up, 0, sizeof(up));
+        if (ctx->fuse_mask) {
+            up.mask = ctx->fuse_mask;
+            up.y0 = ctx->up_tab;
+            up.x0 = ctx->up_tab + ctx->cfg.feat_h + 1;
+            up.H = ctx->H; up.W = ctx->W; up.Hd = ctx->cfg.feat_h; up.Wd = ctx->cfg.feat_w;
+            up.sx = ctx->up_sx;
+        }
         hipLaunchKernelGGL(combine_kernel, cgrid, dim3(256), 0, s, ctx->part, plan->d_off, plan->d_list, d, ctx->HW, a.c, pred,
-                           cls, new_lab_hi, new_lab_lo, prob ? 1 : 0);
+                           cls, new_lab_hi, new_lab_lo, prob ? 1 : 0, up);
     }
     HIP_TRY(ctx, hipGetLastError());
 #ifdef VOSPROP_STAMP
@@ -634,6 +649,7 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
     int rc = ring_alloc(ctx, ctx->ring, cap);
     if (!rc) rc = build_coord_table(ctx);
     if (!rc && hipMalloc((void**)&ctx->pred_buf, (size_t)kMaxClasses * ctx->HW * sizeof(float)) != hipSuccess) rc = VOSPROP_E_HIP;
+    if (!rc && hipMalloc((void**)&ctx->up_tab, (size_t)(cfg->feat_h + cfg->feat_w + 2) * sizeof(int)) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipMalloc((void**)&ctx->cls_tmp, (size_t)ctx->HWp) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipHostMalloc((void**)&ctx->stage_host, (size_t)ctx->HWp, hipHostMallocDefault) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming) != hipSuccess) rc = VOSPROP_E_HIP;
@@ -656,6 +672,7 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     ring_free(ctx->ring);
     ring_free(ctx->scratch);
     if (ctx->coord_tab) (void)hipFree(ctx->coord_tab);
+    if (ctx->up_tab) (void)hipFree(ctx->up_tab);
     if (ctx->part) (void)hipFree(ctx->part);
     for (Plan& p : ctx->plans) {
         if (p.d_off) (void)hipFree(p.d_off);
@@ -697,6 +714,26 @@ static int begin_with_lowres(vosprop_ctx* ctx, const std::vector<uint8_t>& cls, 
     ctx->d = d;
     ctx->H = H;
     ctx->W = W;
+    if (H != ctx->up_H || W != ctx->up_W) {     // new output size: inverse nearest tables for combine_kernel's mask tail
+        const int Hd = ctx->cfg.feat_h, Wd = ctx->cfg.feat_w;
+        ctx->up_sy = (float)Hd / (float)H;
+        ctx->up_sx = (float)Wd / (float)W;
+        ctx->up_host.assign((size_t)Hd + Wd + 2, 0);
+        int y = 0;
+        for (int i = 0; i <= Hd; ++i) {
+            while (y < H && nearest_src(y, Hd, H) < i) ++y;
+            ctx->up_host[i] = y;
+        }
+        int x = 0;
+        for (int i = 0; i <= Wd; ++i) {
+            while (x < W && nearest_src(x, Wd, W) < i) ++x;
+            ctx->up_host[Hd + 1 + i] = x;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->up_tab, ctx->up_host.data(), ctx->up_host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));     // pageable source; only when the output size changes (once per job, normally)
+        ctx->up_H = H;
+        ctx->up_W = W;
+    }
     return VOSPROP_OK;
 }
 
@@ -773,14 +810,17 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     const bool prob = ctx->cfg.probability != 0;
     uint8_t* cls_slot = R.cls + (size_t)slot * ctx->HWp;
     // combine_kernel also writes the new label of this frame (reference inference_utils.py:67-71) into its ring slot
+    const bool fuse_up = mask_out_dev && ctx->cfg.topk == 0;      // dense path: combine_kernel writes the mask itself
+    ctx->fuse_mask = fuse_up ? mask_out_dev : nullptr;
     rc = propagate(ctx, R, slots, n_ref, f, slot, ctx->d, prob, prob, ctx->cfg.sigma1, ctx->cfg.sigma2,
                    ctx->cfg.temperature, ctx->pred_buf, cls_slot, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s);
+    ctx->fuse_mask = nullptr;
     if (rc) return rc;
     if (pred_out_dev)
         HIP_TRY(ctx, hipMemcpyAsync(pred_out_dev, ctx->pred_buf, (size_t)ctx->d * ctx->HW * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (mask_out_dev) {   // reference inference_utils.py:74-75
+    if (mask_out_dev && !fuse_up) {   // reference inference_utils.py:74-75
         hipLaunchKernelGGL(upsample_kernel, dim3((ctx->W + 255) / 256, ctx->H), dim3(256), 0, s, cls_slot, ctx->cfg.feat_h,
-                           ctx->cfg.feat_w, mask_out_dev, ctx->H, ctx->W);
+                           ctx->cfg.feat_w, mask_out_dev, ctx->H, ctx->W, ctx->up_sy, ctx->up_sx);
         HIP_TRY(ctx, hipGetLastError());
     }
     ctx->frame_idx = f + 1;

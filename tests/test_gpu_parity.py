@@ -261,3 +261,28 @@ def test_channels_last_features_are_taken_as_they_are(vos, dev, dtype):
         eng.close()
     for (pa, ma), (pb, mb) in zip(*outs):
         assert torch.equal(pa, pb) and torch.equal(ma, mb)
+
+
+@pytest.mark.parametrize('H,W', [(480, 854), (100, 131), (241, 427), (64, 64)])
+@pytest.mark.parametrize('topk', [0, 5])
+def test_mask_is_the_nearest_upsampling_of_the_class_map(vos, dev, H, W, topk):
+    """The mask a step returns (written by combine_kernel's fused tail on the dense path, by upsample_kernel on the top-k path) is
+    bit for bit F.interpolate(mode='nearest') of the arg-max of the prediction the same step returns (reference
+    inference_utils.py:74-75) - sizes whose ratio is 8, nearly 8, and not an integer; the mask buffer is poisoned first."""
+    Hd, Wd = vos.feature_map_size(H, W)
+    rs = np.random.RandomState(H * 1000 + W)
+    ann = np.zeros((H, W), np.uint8)
+    ann[H // 4:H // 2, W // 4:W // 2] = 1
+    ann[H // 2:, W // 2:] = 2
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=5 if topk else 9, topk=topk)
+    eng.begin_video(ann)
+    for t in range(4):
+        f = torch.from_numpy(rs.randn(256, Hd, Wd).astype(np.float32) * 0.25).to(dev)
+        pred, mask = eng.step(f)
+        if t == 0:
+            continue
+        low = pred.view(-1, Hd, Wd).cpu().argmax(0).to(torch.float32)
+        want = torch.nn.functional.interpolate(low[None, None], size=(H, W), mode='nearest')[0, 0].to(torch.uint8)
+        assert mask.shape == (H, W)
+        assert torch.equal(mask.cpu(), want), float((mask.cpu() != want).float().mean())
+    eng.close()
