@@ -161,7 +161,8 @@ int vosprop_bias_relu_maxpool(const void* x, const void* bias, void* y, int n, i
  * src/model/vos_net.py:27-52) as ONE hipBLASLt GEMM (f32 accumulation) whose epilogue does the rest, so the output is written
  * once.  x (pixels, cin), weight (cout, cin), bias (cout), residual / y (pixels, cout) share `dtype`; bias and residual may be
  * NULL; residual may alias y.  The first call for a problem (pixels, cin, cout, epilogue) times the library's candidate algorithms
- * on the operands (not inside a stream capture); an algorithm is never reused for another problem size.  The calls for one device
+ * on the operands (not inside a stream capture) and records which one won in $VOSPROP_CACHE_DIR (default ~/.cache/vosprop;
+ * VOSPROP_PW_CACHE=0: off) so that later processes skip the timing; an algorithm is never reused for another problem size.  The calls for one device
  * share one library workspace: keep them stream-ordered (one stream at a time, as the encoder wrapper does).  VOSPROP_E_UNSUPPORTED: the library has no kernel for the shape - use a convolution + vosprop_bias_act. */
 int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, const void* residual, void* y,
                            long long pixels, int cin, int cout, int relu, int dtype, void* stream);

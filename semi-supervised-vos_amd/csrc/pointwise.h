@@ -10,8 +10,13 @@
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -32,12 +37,56 @@ struct PwDevice {
     hipblasLtHandle_t handle = nullptr;
     void* workspace = nullptr;
     size_t ws_bytes = 0;
+    std::string ident;     // device name + library version, for the rank cache key
     // (pixels, cin, cout, dtype, epilogue, residual) -> plan
     std::map<std::tuple<long long, int, int, int, int, int>, PwPlan> plans;
 };
 
 inline std::mutex& pw_mutex() { static std::mutex m; return m; }
 inline std::map<int, PwDevice>& pw_devices() { static std::map<int, PwDevice> d; return d; }
+
+// Which of the library's ranked candidates won the timing, per exact problem, remembered across processes: the next process asks
+// the library for the same ranked list (milliseconds) and takes the remembered rank instead of timing 48 candidates again (~0.5 s,
+// a fifth of a DAVIS-sized job).  The algorithm itself is always a fresh answer of the library for the exact problem; the key holds
+// the device name and the library version, so another stack simply searches again.  One text line per entry, appended with a single
+// write (safe with one process per GPU).  $VOSPROP_CACHE_DIR or ~/.cache/vosprop; VOSPROP_PW_CACHE=0 turns it off.
+struct PwRankCache {
+    bool loaded = false, enabled = true;
+    std::string file;
+    std::map<std::string, int> rank;
+};
+inline PwRankCache& pw_rank_cache() { static PwRankCache c; return c; }
+
+inline void pw_rank_cache_load(PwRankCache& c) {
+    c.loaded = true;
+    const char* off = getenv("VOSPROP_PW_CACHE");
+    if (off && off[0] == '0') { c.enabled = false; return; }
+    std::string dir;
+    if (const char* d = getenv("VOSPROP_CACHE_DIR")) dir = d;
+    else if (const char* h = getenv("HOME")) {
+        dir = std::string(h) + "/.cache";
+        (void)mkdir(dir.c_str(), 0755);
+        dir += "/vosprop";
+    } else { c.enabled = false; return; }
+    (void)mkdir(dir.c_str(), 0755);
+    c.file = dir + "/pointwise_ranks_v1.txt";
+    if (FILE* f = fopen(c.file.c_str(), "r")) {
+        char key[512];
+        int r;
+        while (fscanf(f, "%511s %d", key, &r) == 2) c.rank[key] = r;
+        fclose(f);
+    }
+}
+
+inline void pw_rank_cache_store(PwRankCache& c, const std::string& key, int r) {
+    if (!c.enabled || c.file.empty()) return;
+    c.rank[key] = r;
+    const std::string line = key + " " + std::to_string(r) + "\n";
+    const int fd = open(c.file.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+    if (fd < 0) return;
+    (void)!write(fd, line.data(), line.size());
+    close(fd);
+}
 
 inline bool pw_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -73,7 +122,18 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
     std::lock_guard<std::mutex> lock(pw_mutex());
     PwDevice& D = pw_devices()[dev];
     const bool capturing = pw_capturing(s);
-    if (!D.handle && hipblasLtCreate(&D.handle) != HIPBLAS_STATUS_SUCCESS) return 2;
+    if (!D.handle) {
+        if (hipblasLtCreate(&D.handle) != HIPBLAS_STATUS_SUCCESS) return 2;
+        hipDeviceProp_t prop;
+        int ver = 0;
+        (void)hipblasLtGetVersion(D.handle, &ver);
+        D.ident = "unknown";
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) D.ident = std::string(prop.name) + ":" + prop.gcnArchName;
+        else (void)hipGetLastError();
+        for (char& ch : D.ident)
+            if (ch == ' ' || ch == '\t' || ch == '\n') ch = '_';
+        D.ident += ":lt" + std::to_string(ver);
+    }
     if (!D.workspace && !capturing) {
         if (hipMalloc(&D.workspace, kPwWorkspace) == hipSuccess) D.ws_bytes = kPwWorkspace;
         else { (void)hipGetLastError(); D.workspace = nullptr; }
@@ -121,10 +181,26 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
         hipblasLtMatmulPreferenceDestroy(pref);
         if (hs != HIPBLAS_STATUS_SUCCESS || got <= 0) return 3;
         int best = -1;
+        PwRankCache& RC = pw_rank_cache();
+        if (!RC.loaded) pw_rank_cache_load(RC);
+        const std::string ckey = D.ident + "|" + std::to_string(pixels) + "|" + std::to_string(cin) + "|" + std::to_string(cout) + "|" +
+                                 std::to_string(dtype_key) + "|" + std::to_string(ep_key) + "|" + (residual ? "r" : "-") + "|" +
+                                 std::to_string(want);
+        int cached_rank = -1;
+        if (RC.enabled) {
+            auto it = RC.rank.find(ckey);
+            if (it != RC.rank.end()) cached_rank = it->second;
+        }
         if (capturing || residual == y) {
             // no timing inside a capture (or when a timing run would accumulate into its own input): first candidate that fits
             for (int i = 0; i < got && best < 0; ++i)
                 if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= D.ws_bytes) best = i;
+        } else if (cached_rank >= 0 && cached_rank < got && res[cached_rank].state == HIPBLAS_STATUS_SUCCESS &&
+                   res[cached_rank].workspaceSize <= D.ws_bytes) {
+            best = cached_rank;      // timed by an earlier process on this stack
+            P.tuned = true;
+            if (getenv("VOSPROP_PW_VERBOSE"))
+                fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d: rank #%d from %s\n", pixels, cin, cout, best, RC.file.c_str());
         } else {
             // the library's ranking is a model (the winners measured on MI355X sit at ranks 2-43): time its candidates once on
             // the real operands - the output is simply rewritten
@@ -154,6 +230,7 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             P.tuned = best >= 0;
+            if (best >= 0) pw_rank_cache_store(RC, ckey, best);
             if (getenv("VOSPROP_PW_VERBOSE"))
                 fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d (bias %d relu %d residual %d): %d candidates, #%d wins, %.1f us\n",
                         pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, best, best_ms * 1e3f);

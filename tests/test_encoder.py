@@ -225,3 +225,37 @@ def test_stem_bias_relu_maxpool_kernel(dtype):
         got = vn.bias_relu_maxpool(y, b, pool)
         assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
         assert torch.equal(got, want), (n, c, h, w, float((got.float() - want.float()).abs().max()))
+
+
+@pytest.mark.gpu
+def test_pointwise_rank_cache_across_processes(tmp_path):
+    """The winner's rank in the library's candidate list is remembered per exact problem ($VOSPROP_CACHE_DIR): a second process
+    takes it over without timing, and computes the same result; VOSPROP_PW_CACHE=0 writes nothing."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import importlib, torch\n"
+        "vn = importlib.import_module('semi-supervised-vos_amd.vos_net')\n"
+        "torch.manual_seed(0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "conv = torch.nn.Conv2d(64, 128, 1).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)\n"
+        "x = torch.randn(2, 64, 20, 30, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)\n"
+        "with torch.no_grad():\n"
+        "    y = vn.conv_bias_act(x, conv, conv.bias.detach(), None, True)\n"
+        "print('SUM', float(y.float().sum()))\n")
+    root = str(Path(__file__).resolve().parent.parent)
+    env = dict(os.environ, VOSPROP_CACHE_DIR=str(tmp_path), VOSPROP_PW_VERBOSE='1', PYTHONPATH=root)
+    runs = [subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+            for _ in range(2)]
+    assert all(r.returncode == 0 for r in runs), runs[0].stderr[-400:] + runs[1].stderr[-400:]
+    cache = tmp_path / 'pointwise_ranks_v1.txt'
+    assert cache.exists() and len(cache.read_text().strip().splitlines()) == 1
+    assert 'candidates' in runs[0].stderr and 'rank #' not in runs[0].stderr          # first process: timed
+    assert 'rank #' in runs[1].stderr and 'candidates' not in runs[1].stderr          # second: taken from the cache
+    assert [l for l in runs[0].stdout.splitlines() if l.startswith('SUM')] == [l for l in runs[1].stdout.splitlines() if l.startswith('SUM')]
+    off = tmp_path / 'off'
+    off.mkdir()
+    r = subprocess.run([sys.executable, '-c', code], env=dict(env, VOSPROP_CACHE_DIR=str(off), VOSPROP_PW_CACHE='0'), cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and not list(off.iterdir())
