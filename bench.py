@@ -233,6 +233,20 @@ def main():
     torch.cuda.synchronize()
     prop_fps = 50 / (time.perf_counter() - t1)
 
+    # the encoder alone: the look-ahead batch replayed 5 times back to back (same graph, same input shape as the timed region)
+    idx = torch.arange(min(B, args.steps), device=dev) % pool
+    xb = clip.index_select(0, idx).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        net(xb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            net(xb)
+        e1.record()
+    torch.cuda.synchronize()
+    encoder_us = e0.elapsed_time(e1) / 5 / xb.shape[0] * 1e3
+    del xb
+
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them, in
     # their own passes), so the line carries the committed measurement for this workload (tools/traffic_pmc.sh) or null
     traffic, traffic_src, pmc = None, None, {}
@@ -255,7 +269,7 @@ def main():
                        'frame_range': cfg['frame_range'], 'topk': wl['topk'], 'encoder': wl['model'],
                        'encoder_dtype': args.encoder_dtype, 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
-            'propagation_only_frames_per_s_per_gpu': prop_fps,
+            'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us,
             'roofline': {'kernel': 'prop_bf16_kernel', 'bound': 'mfma', 'achieved': achieved,
                          'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us,
