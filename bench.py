@@ -3,8 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (N > 1: launched by torch.distributed.run; videos shard across ranks with no data-path
-collective - every rank runs its own synthetic clip, "weak" scaling).  A step = one frame of BASELINE.json
+One process per GPU.  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or plainly as `python bench.py --gpus N` - then this process starts
+the N rank processes itself BEFORE it touches any GPU (a process that has initialised HIP must never exec) and passes rank 0's JSON
+line through.  Videos shard across ranks with no data-path collective - every rank runs its own synthetic clip, "weak" scaling;
+RCCL carries only the barrier and the max-reduce of the wall time.  A step = one frame of BASELINE.json
 configs[1] (DAVIS-2017-shaped 480p clip, ResNet-50 encoder, dense affinity, ref_num 9): encoder forward on
 PyTorch-ROCm + the hand-written HIP propagation (push, fused affinity/softmax/prior/label kernel, combine,
 label pack, mask up-sample).  Frames are resident in HBM before the timed region; masks stay in HBM.
@@ -56,14 +59,25 @@ def synthetic_clip(H, W, n_frames, seed, device):
     return clip, ann
 
 
-def cpu_baseline(wl, cfg, model_state, feats_hist, labels_hist_cls, ann, frames_cpu, n_time=4):
-    """The oracle (torch-CPU restatement of the reference, oracle/vos_oracle.py) + the same encoder on the host
-    cores, on a bounded sample: `n_time` frames at frame_idx >= 20 (N = 9)."""
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(wl, cfg, model_state, feats_hist, labels_hist_cls, ann, frames_cpu, n_time=5, n_time_1t=2):
+    """the oracle (torch-CPU restatement of the reference, oracle/vos_oracle.py) + the same encoder in
+    fp32 on the host cores, on a bounded sample of the bench clip: `n_time` warm frames at frame_idx >= 20 (N = ref_num, both
+    sigma branches live) with all cores of this job's share, MEDIAN per-frame time, encoder and propagation timed separately;
+    then `n_time_1t` frames on ONE thread.  CPU model and core count are part of the record."""
     from oracle import vos_oracle as vo
     vos_net = importlib.import_module('semi-supervised-vos_amd.vos_net')
     # the GPU box gives one GPU's job a 16-core share (os.cpu_count() reports the whole host)
     threads = min(16, len(os.sched_getaffinity(0)))
-    torch.set_num_threads(threads)
     net = vos_net.VOSNet(wl['model'])
     net.load_state_dict(model_state)
     net.eval()
@@ -74,17 +88,36 @@ def cpu_baseline(wl, cfg, model_state, feats_hist, labels_hist_cls, ann, frames_
     oh.scatter_(0, labels_hist_cls.long().unsqueeze(0), 1.0)
     st.label_history = oh
     st.frame_idx = T0
-    times = []
-    with torch.no_grad():
-        for i in range(n_time + 1):
-            t0 = time.perf_counter()
-            f = net(frames_cpu[i:i + 1])
-            vo.rollout_step(st, f, cfg['frame_range'], wl['ref_num'], cfg['temperature'])
-            times.append(time.perf_counter() - t0)
-    dt = float(np.mean(times[1:]))
-    return {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_time} frames (after 1 untimed) of {wl["model"]} encoder + oracle predict at frame_idx '
-                      f'{T0 + 1}..{T0 + n_time}, N={wl["ref_num"]}, fp32, torch {threads} threads'}
+
+    def run(n_frames, first):
+        enc, prop = [], []
+        with torch.no_grad():
+            for i in range(first, first + n_frames):
+                t0 = time.perf_counter()
+                f = net(frames_cpu[i % frames_cpu.shape[0]][None])
+                t1 = time.perf_counter()
+                vo.rollout_step(st, f, cfg['frame_range'], wl['ref_num'], cfg['temperature'])
+                t2 = time.perf_counter()
+                enc.append(t1 - t0)
+                prop.append(t2 - t1)
+        return np.asarray(enc), np.asarray(prop)
+
+    torch.set_num_threads(threads)
+    run(1, 0)                                     # untimed: allocator, thread pool, oneDNN primitives
+    enc, prop = run(n_time, 1)
+    dt = float(np.median(enc + prop))
+    torch.set_num_threads(1)
+    enc1, prop1 = run(n_time_1t, 1 + n_time)
+    dt1 = float(np.median(enc1 + prop1))
+    torch.set_num_threads(threads)
+    return {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': threads, 'kind': 'port', 'cpu_model': cpu_model_name(),
+            'host_cores_visible': len(os.sched_getaffinity(0)),
+            'propagation_only_frames_per_s': 1.0 / float(np.median(prop)), 'encoder_ms': float(np.median(enc)) * 1e3,
+            'one_thread': {'value': 1.0 / dt1, 'unit': 'frames/s', 'cores': 1, 'frames': n_time_1t,
+                           'propagation_only_frames_per_s': 1.0 / float(np.median(prop1))},
+            'sample': f'median of {n_time} warm frames (after 1 untimed) of the fp32 {wl["model"]} encoder + oracle predict + argmax + '
+                      f'up-sample at frame_idx {T0 + 1}..{T0 + n_time}, N={wl["ref_num"]}, torch {threads} threads; then '
+                      f'{n_time_1t} frames on 1 thread'}
 
 
 def mask_parity(wl, cfg, ann, feats, gpu_masks, n_frames=7):
@@ -103,14 +136,139 @@ def mask_parity(wl, cfg, ann, feats, gpu_masks, n_frames=7):
             'what': 'engine masks vs oracle (torch-CPU restatement of the reference) on identical bf16 encoder features'}
 
 
+def end_to_end_leg(args, wl, dev, clip, pool, net, eng, enc_dtype, fence, world, on_gloo):
+    """K frames from host memory to host memory: uint8 HWC frames (what a JPEG decoder hands over) sit in PINNED host memory, go
+    over PCIe batch by batch on a copy stream one batch ahead of the compute stream, are normalised on the device with the
+    reference's ToTensor + Normalize (datasets.normalize_on_device: bit-identical table look-up), encoded, propagated, and every
+    mask is copied back into pinned host memory.  The clock stops when the last mask is on the host."""
+    ds = importlib.import_module('semi-supervised-vos_amd.datasets')
+    H, W, B, K = wl['H'], wl['W'], max(1, args.encoder_batch), args.steps
+    mean = torch.tensor(ds.IMAGENET_MEAN, device=dev).view(1, 3, 1, 1)
+    std = torch.tensor(ds.IMAGENET_STD, device=dev).view(1, 3, 1, 1)
+    u8 = ((clip.float() * std + mean) * 255.0).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    frames_host = torch.empty(u8.shape, dtype=torch.uint8).pin_memory()
+    frames_host.copy_(u8)
+    del u8
+    masks_host = torch.empty((K, H, W), dtype=torch.uint8).pin_memory()
+    bufs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    copied = [torch.cuda.Event(), torch.cuda.Event()]
+    consumed = [torch.cuda.Event(), torch.cuda.Event()]
+    copy_stream = torch.cuda.Stream(dev)
+    main = torch.cuda.current_stream(dev)
+
+    def upload(k):            # batch k -> bufs[k % 2] on the copy stream, after the batch that used that buffer was normalised
+        n = min(B, K - k * B)
+        with torch.cuda.stream(copy_stream):
+            if k >= 2:
+                copy_stream.wait_event(consumed[k % 2])
+            for i in range(n):
+                bufs[k % 2][i].copy_(frames_host[(k * B + i) % pool], non_blocking=True)
+            copied[k % 2].record(copy_stream)
+        return n
+
+    n_batches = (K + B - 1) // B
+    fence()
+    t0 = time.perf_counter()
+    upload(0)
+    for k in range(n_batches):
+        n = min(B, K - k * B)
+        if k + 1 < n_batches:
+            upload(k + 1)
+        main.wait_event(copied[k % 2])
+        with torch.no_grad():
+            x = ds.normalize_on_device(bufs[k % 2][:n]).to(enc_dtype).contiguous(memory_format=torch.channels_last)
+            consumed[k % 2].record(main)
+            feats = net(x)
+        for i in range(n):
+            _, mask = eng.step(feats[i][None], want_pred=False, want_mask=True)
+            masks_host[k * B + i].copy_(mask, non_blocking=True)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device='cpu' if on_gloo else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return {'value': world * K / dt, 'unit': 'frames/s', 'steps': K, 'ms_per_step': dt / K * 1e3,
+            'bytes_over_pcie_per_frame': H * W * 3 + H * W,
+            'what': 'uint8 HWC frames in pinned host memory -> H2D (copy stream, one batch ahead) -> ToTensor + Normalize on the '
+                    'device -> encoder -> propagation -> mask -> D2H into pinned host memory; clock stops with the last mask on the host',
+            'mask_checksum': int(masks_host[-1].to(torch.int64).sum())}
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, extra_env=None):
+    """`python bench.py --gpus N` without a launcher around it: start the N rank processes (the same command line, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rendezvous on 127.0.0.1) from a parent that has NOT touched
+    the GPU - fresh children, never an exec of a process that has initialised HIP.  Rank r uses the r-th visible device
+    (LOCAL_RANK = r; an inherited HIP_VISIBLE_DEVICES is kept as it is, so the ordinals index into it).  Rank 0's stdout (the
+    single JSON line) is passed through; the exit code is the first non-zero one of the ranks."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script or str(Path(__file__).resolve())] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        pr.wait()
+        rc = rc or pr.returncode
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+def stub_main(args, rank, world):
+    """`--workload stub_cpu`: the rank protocol of the bench (rendezvous, fence, K timed steps, max-over-ranks, one JSON line from
+    rank 0) around a trivial CPU step under gloo - what tests/test_bench_launcher.py drives on a box without GPUs."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('gloo')
+    x = torch.ones(64, 64)
+    for _ in range(args.warmup):
+        x = (x @ x) / 64.0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = (x @ x) / 64.0
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'stub steps/sec', 'value': world * args.steps / dt, 'unit': 'steps/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': 'stub_cpu'}, 'checksum': float(x.sum())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=384)
     ap.add_argument('--warmup', type=int, default=64)
-    ap.add_argument('--workload', default='davis480p_r50_dense', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='davis480p_r50_dense', choices=sorted(WORKLOADS) + ['stub_cpu'])
     ap.add_argument('--encoder-dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='barrier / max-reduce transport for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-end-to-end', action='store_true', help='skip the host-to-host leg (uint8 frames in pinned memory -> masks in pinned memory)')
     ap.add_argument('--no-encoder-graph', action='store_true', help='run the encoder as eager kernel launches')
     ap.add_argument('--no-miopen-find', action='store_true',
                     help='take MIOpen\'s immediate-mode convolution algorithms instead of letting it time its solvers in the warm-up')
@@ -119,15 +277,31 @@ def main():
                     help='frames encoded per encoder call (features do not depend on the propagated labels)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher around us: become one.  Nothing in this process has touched a GPU yet (importing torch does not).
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: start me as `python bench.py --gpus N` (I launch the ranks) '
+                         f'or under torch.distributed.run with --nproc-per-node N')
+    if args.workload == 'stub_cpu':
+        return stub_main(args, rank, world)
+    # VOSPROP_BENCH_DEVICES="0,0": device ordinal per local rank (rehearsing the N > 1 protocol on a box with fewer GPUs; RCCL
+    # refuses two ranks on one device, so that rehearsal runs with --dist-backend gloo)
+    devmap = [int(d) for d in os.environ.get('VOSPROP_BENCH_DEVICES', '').split(',') if d.strip() != '']
+    local_dev = devmap[local % len(devmap)] if devmap else local
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
+    on_gloo = args.dist_backend == 'gloo'
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if on_gloo:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
+    local = local_dev
 
     vos = importlib.import_module('semi-supervised-vos_amd')
     vos_net = importlib.import_module('semi-supervised-vos_amd.vos_net')
@@ -212,7 +386,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device='cpu' if on_gloo else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -247,16 +421,26 @@ def main():
     encoder_us = e0.elapsed_time(e1) / 5 / xb.shape[0] * 1e3
     del xb
 
+    # ---- end to end, host to host: uint8 frames in pinned host memory -> H2D -> normalise -> encoder ->
+    # propagate -> mask -> D2H into pinned host memory.  Reported beside `value`, never as `value`.
+    end_to_end = None
+    if not args.no_end_to_end and wl['topk'] == 0:
+        end_to_end = end_to_end_leg(args, wl, dev, clip, pool, net, eng, enc_dtype, fence, world, on_gloo)
+
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them, in
     # their own passes), so the line carries the committed measurement for this workload (tools/traffic_pmc.sh) or null
     traffic, traffic_src, pmc = None, None, {}
-    tj = Path(__file__).resolve().parent / 'profiles' / 'r01_prop_kernel_traffic.json'
-    if args.workload == 'davis480p_r50_dense' and tj.exists():
+    prof = Path(__file__).resolve().parent / 'profiles'
+    for tj in (prof / f'r02_prop_kernel_traffic_{args.workload}.json',
+               prof / 'r01_prop_kernel_traffic.json' if args.workload == 'davis480p_r50_dense' else None):
+        if tj is None or not tj.exists():
+            continue
         try:
             t = json.loads(tj.read_text())
             traffic = float(t['traffic_bytes_per_launch'])
-            traffic_src = 'profiles/r01_prop_kernel_traffic.json: ' + t['how']
+            traffic_src = f'profiles/{tj.name}: ' + t['how']
             pmc = {k: t[k] for k in ('mfma_busy_frac', 'l2_hit_rate', 'hbm_gb_per_s', 'counters_source') if k in t}
+            break
         except Exception:
             traffic = None
     if rank == 0:
@@ -269,7 +453,7 @@ def main():
                        'frame_range': cfg['frame_range'], 'topk': wl['topk'], 'encoder': wl['model'],
                        'encoder_dtype': args.encoder_dtype, 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
-            'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us,
+            'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us, 'end_to_end': end_to_end,
             'roofline': {'kernel': 'prop_bf16_kernel', 'bound': 'mfma', 'achieved': achieved,
                          'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us,
@@ -284,7 +468,7 @@ def main():
             src_r, src_c = vo.nearest_src_index(Hd, H), vo.nearest_src_index(Wd, W)
             cls0 = ann_cls[src_r][:, src_c].reshape(-1)
             cls_hist = torch.stack([cls0] + [c for c in keep_cls[1:]], 0)
-            frames_cpu = clip[0:6].float().cpu().contiguous()
+            frames_cpu = clip[0:8].float().cpu().contiguous()
             out['cpu_baseline'] = cpu_baseline(wl, cfg, model_state, fh, cls_hist, ann, frames_cpu)
             out['mask_parity'] = mask_parity(wl, cfg, ann, fh, keep_masks)
         else:

@@ -72,7 +72,7 @@ typedef struct vosprop_config {
     int topk;             /* 0 = dense (the reference); 1..32 = keep the k largest A[.,t] per target pixel, zero the rest,
                              no renormalisation (NOT in the reference; label-propagation mode only; two kernel passes) */
     int precision;        /* VOSPROP_PREC_*                                                      */
-    int ring_capacity;    /* 0 = auto: max(frame_range + 4, ref_num) + 1 frames                  */
+    int ring_capacity;    /* 0 = auto: max(frame_range + 4, ref_num) + 1 frames; anything smaller is VOSPROP_E_INVALID */
     int reserved[8];      /* zero                                                                */
 } vosprop_config;
 
@@ -133,7 +133,7 @@ int vosprop_frame_index(const vosprop_ctx* ctx);
  *   target_dev    (C, H_d, W_d)
  *   ref_label_dev (d, T, H_d*W_d)    f32 (one-hot or probabilities)
  *   out_dev       (d, H_d*W_d)       f32
- * Uses ctx's GPU, precision, top-k and scratch ring; ctx must have ring_capacity >= ref_num + 1.
+ * Uses ctx's GPU, precision, top-k and a scratch ring of its own (sized by the number of frames the sampler returns).
  * Does not touch the video state of ctx. */
 int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_dev, int feat_dtype,
                     const float* ref_label_dev, int T, int d, int frame_idx, int frame_range, int ref_num,
@@ -160,15 +160,22 @@ int vosprop_bias_relu_maxpool(const void* x, const void* bias, void* y, int n, i
  * `adjust_dim` together with the BatchNorm shift, `out += identity` and ReLU that follow them (src/model/backbone/resnet.py:66-95,
  * src/model/vos_net.py:27-52) as ONE hipBLASLt GEMM (f32 accumulation) whose epilogue does the rest, so the output is written
  * once.  x (pixels, cin), weight (cout, cin), bias (cout), residual / y (pixels, cout) share `dtype`; bias and residual may be
- * NULL; residual may alias y.  The first call for a problem (pixels, cin, cout, epilogue) times the library's candidate algorithms
- * on the operands (not inside a stream capture) and records which one won in $VOSPROP_CACHE_DIR (default ~/.cache/vosprop;
- * VOSPROP_PW_CACHE=0: off) so that later processes skip the timing; an algorithm is never reused for another problem size.  The calls for one device
- * share one library workspace: keep them stream-ordered (one stream at a time, as the encoder wrapper does).  VOSPROP_E_UNSUPPORTED: the library has no kernel for the shape - use a convolution + vosprop_bias_act. */
+ * NULL; residual may alias y.  The first call for a problem (pixels, cin, cout, epilogue) - never inside a stream capture - computes
+ * an f32 reference of up to 1 024 sampled output rows, runs the library's candidate algorithms on the operands, and lets only those
+ * whose output agrees with the reference within the rounding of the output type compete on time (a fast candidate with wrong or
+ * sloppy numerics can never win); the winner gets a workspace of its own.  Which algorithm won is remembered by its library
+ * solution index in $VOSPROP_CACHE_DIR (default ~/.cache/vosprop; VOSPROP_PW_CACHE=0: off); a later process re-validates the
+ * remembered algorithm against the reference before trusting it.  An algorithm is never reused for another problem size.  Keep the
+ * calls for one device stream-ordered (one stream at a time, as the encoder wrapper does).  VOSPROP_E_UNSUPPORTED: the library has
+ * no validated kernel for the shape, or the first call for the problem came inside a stream capture - use a convolution +
+ * vosprop_bias_act. */
 int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, const void* residual, void* y,
                            long long pixels, int cin, int cout, int relu, int dtype, void* stream);
 
 /* Frame sampler, reference `sample_frames` (src/model/predict.py:74-89).  Host-side, exact.
- * out must hold num_refs ints (or frame_idx when frame_idx <= num_refs); returns the count. */
+ * out must hold max(num_refs, 3) ints (or frame_idx when frame_idx <= num_refs); returns the count - for num_refs == 3 past
+ * frame 3 that is the 3 "continuous" frames alone.  num_refs < 3 past frame num_refs: VOSPROP_E_INVALID (the reference's
+ * np.linspace is asked for a negative number of samples and raises ValueError). */
 int vosprop_sample_frames(int frame_idx, int frame_range, int num_refs, int* out);
 
 /* Timing / introspection of the last propagation on ctx (for bench.py and the roofline line). */

@@ -16,8 +16,6 @@
 #include "aux_kernels.h"
 #include "common.h"
 #include "prop_bf16.h"
-#include "prop_bf16_v5.h"
-#include "prop_bf16_v6.h"
 #include "pointwise.h"
 #include "encoder_ops.h"
 
@@ -317,20 +315,6 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream
     const dim3 grid(lp.grid), block(kWaves * 64);
     if (mode == 1) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 1>), grid, block, 0, s, a); return; }
     if (mode == 2) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 2>), grid, block, 0, s, a); return; }
-    // prop_bf16_v5_kernel (one wave per SIMD, inline-asm MFMAs, row-interleaved softmax) is correct but still slower than the
-    // 8-wave kernel (336 vs 274 us at 480p); it is kept selectable for the next round's work
-    static const bool use_v5 = getenv("VOSPROP_V5") != nullptr;
-    if (!lp.prob && !lp.lab_lo && use_v5) {
-        hipLaunchKernelGGL(prop_bf16_v5_kernel, grid, dim3(kW5 * 64), 0, s, a);
-        return;
-    }
-    // prop_bf16_v6_kernel (4 waves x 64 columns, everything inline asm, softmax of the previous tile under the chains): same
-    // results, same speed as the 8-wave kernel; selectable for experiments (see its header and DESIGN.md 4.5)
-    static const bool use_v6 = getenv("VOSPROP_V6") != nullptr;
-    if (!lp.prob && !lp.lab_lo && use_v6) {
-        hipLaunchKernelGGL(prop_bf16_v6_kernel, grid, dim3(kW6 * 64), 0, s, a);
-        return;
-    }
     if (lp.prob) {
         if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<true, true, 0>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((prop_bf16_kernel<true, false, 0>), grid, block, 0, s, a);
@@ -582,6 +566,27 @@ int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, 
     }
 }
 
+/* test hook (GPU): every candidate algorithm the library returns for one pointwise-convolution problem, each timed and checked
+ * against the f32 reference of csrc/pointwise.h on a zeroed and on a 0xFF-filled workspace.  rows: vosprop::PwCandidateReport
+ * (index, workspace bytes, microseconds, worst err/tol clean, worst err/tol dirty, name[160]).  Returns the number of rows, or a
+ * negative VOSPROP_E_* code.  Changes no plan. */
+int vosprop_debug_pointwise_candidates(const void* x, const void* weight, const void* bias, const void* residual, void* y,
+                                       long long pixels, int cin, int cout, int relu, int dtype, void* stream, void* rows,
+                                       int cap_rows) {
+    hipDataType dt;
+    switch (dtype) {
+        case VOSPROP_DT_BF16: dt = HIP_R_16BF; break;
+        case VOSPROP_DT_F16: dt = HIP_R_16F; break;
+        case VOSPROP_DT_F32: dt = HIP_R_32F; break;
+        default: return VOSPROP_E_INVALID;
+    }
+    int n = 0;
+    const int rc = pointwise_conv(x, weight, bias, residual, y, pixels, cin, cout, relu, dt, dtype, (hipStream_t)stream,
+                                  (PwCandidateReport*)rows, cap_rows, &n);
+    if (rc == 0) return n;
+    return rc == 1 ? VOSPROP_E_INVALID : rc == 3 ? VOSPROP_E_UNSUPPORTED : VOSPROP_E_HIP;
+}
+
 /* test hook (no GPU needed): segment table for TT target tiles x NT reference tiles; rows of out = (workgroup, tt, r_lo, n_steps) */
 int vosprop_debug_plan(int TT, int NT, int streamk, int* out, int cap_rows) {
     std::vector<std::vector<Segment>> per_wg;
@@ -606,6 +611,7 @@ int vosprop_sample_frames(int frame_idx, int frame_range, int num_refs, int* out
     }
     const int dense_num = kContinuousFrame - 1;
     const int sparse_num = num_refs - dense_num;
+    if (sparse_num < 0) return VOSPROP_E_INVALID;   // the reference's np.linspace(.., num=-1 / -2) raises ValueError here
     const int ref_end = frame_idx - dense_num - 1;
     const int ref_start = ref_end - frame_range > 0 ? ref_end - frame_range : 0;
     if (sparse_num == 1) {
@@ -644,7 +650,7 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
     int cap = cfg->ring_capacity;
     const int need = (cfg->frame_range + kContinuousFrame > cfg->ref_num ? cfg->frame_range + kContinuousFrame : cfg->ref_num) + 1;
     if (cap == 0) cap = need;
-    if (cap < cfg->ref_num + 1) { delete ctx; return VOSPROP_E_INVALID; }
+    if (cap < need) { delete ctx; return VOSPROP_E_INVALID; }   // vosprop_step reaches frame_idx - 4 - frame_range: fewer slots alias
     ctx->cfg.ring_capacity = cap;
     int rc = ring_alloc(ctx, ctx->ring, cap);
     if (!rc) rc = build_coord_table(ctx);
@@ -806,6 +812,8 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     }
     int idx[kMaxRef], slots[kMaxRef];
     const int n_ref = vosprop_sample_frames(f, ctx->cfg.frame_range, ctx->cfg.ref_num, idx);
+    if (n_ref < 1)
+        return fail(ctx, VOSPROP_E_INVALID, "ref_num < 3 cannot sample past frame ref_num (the reference's np.linspace raises)");
     for (int n = 0; n < n_ref; ++n) slots[n] = idx[n] % R.cap;
     const bool prob = ctx->cfg.probability != 0;
     uint8_t* cls_slot = R.cls + (size_t)slot * ctx->HWp;
@@ -836,15 +844,18 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
     if (d < 1 || d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "d > VOSPROP_MAX_CLASSES");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(ctx, hipSetDevice(ctx->cfg.device));
-    if (ctx->scratch.cap < ref_num + 1) {
+    std::vector<int> idx((size_t)(frame_idx > ref_num ? frame_idx : ref_num) + kContinuousFrame);
+    const int n_ref = vosprop_sample_frames(frame_idx, frame_range, ref_num, idx.data());
+    if (n_ref < 1)
+        return fail(ctx, VOSPROP_E_INVALID, "ref_num < 3 cannot sample past frame ref_num (the reference's np.linspace raises)");
+    if (n_ref > kMaxRef) return fail(ctx, VOSPROP_E_INVALID, "more than VOSPROP_MAX_REF sampled frames");
+    if (ctx->scratch.cap < n_ref + 1) {      // sized by what the sampler RETURNS (never by ref_num alone)
         HIP_TRY(ctx, hipDeviceSynchronize());
         ring_free(ctx->scratch);
-        int rc = ring_alloc(ctx, ctx->scratch, ref_num + 1);
+        int rc = ring_alloc(ctx, ctx->scratch, (n_ref > ref_num ? n_ref : ref_num) + 1);
         if (rc) return rc;
     }
     Ring& R = ctx->scratch;
-    std::vector<int> idx((size_t)(frame_idx > ref_num ? frame_idx : ref_num));
-    const int n_ref = vosprop_sample_frames(frame_idx, frame_range, ref_num, idx.data());
     const size_t esz = dtype_size(feat_dtype);
     const size_t frame_elems = (size_t)kC * ctx->HW;
     const size_t lab_slot = (size_t)ctx->tiles * 2 * 64 * 8;

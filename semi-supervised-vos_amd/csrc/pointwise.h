@@ -6,9 +6,27 @@
 // output once instead of write + read + write (convolution, then vosprop_bias_act).  hipBLASLt is column-major, so the
 // row-major product is issued transposed:  D^T (cout x pixels) = W (cout x cin) * X^T (cin x pixels), i.e. op(A) = T on the
 // weight, op(B) = N on the activations, bias broadcast along the rows of D^T (= output channels), C = residual with beta = 1.
+//
+// Which library algorithm runs is decided ONCE per exact problem, and NUMERICS GATE SPEED (round-1 lesson: the fastest of the
+// library's candidates for 109 140 x 256 -> 1024 + residual + ReLU returned values 6 half-ulps off on a fresh box):
+//   1. an f32 reference of up to 1 024 sampled output rows (the first 128, the last 512 - where ragged tail tiles live - and 384
+//      spread over the middle), all output channels, is computed by a plain HIP kernel of this file (pw_ref_kernel: sequential
+//      fmaf over cin, + bias + residual, ReLU) together with a per-element tolerance
+//          tol = eps_out * |ref| + eps_acc * sum|x w| ,  eps_out = 2 roundings of the output type, eps_acc = 2^-18;
+//   2. every candidate runs on a ZEROED workspace (split-K / stream-K kernels keep flags and partial tiles there), warm + timed
+//      launches back to back WITHOUT re-zeroing (so a kernel that does not clean up after itself shows), and its LAST output is
+//      compared with the reference (pw_cmp_kernel); only candidates within tolerance may win the timing;
+//   3. the winner gets a workspace OF ITS OWN (zeroed once) - no other algorithm ever scribbles over its flags;
+//   4. what is remembered across processes is the algorithm's IDENTITY (library solution index) per exact problem, device,
+//      library version and workspace limit; a cached algorithm is re-checked by the library (matmulIsAlgoSupported) and
+//      RE-VALIDATED against the reference once before it is trusted.
+// Nothing is tuned or validated inside a stream capture: a problem without a validated plan reports "unsupported" there and the
+// caller takes the convolution + vosprop_bias_act path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -22,22 +40,88 @@
 #include <tuple>
 #include <vector>
 
+#include "common.h"
+
 namespace vosprop {
 
+// ---------------------------------------------------------------------------------------------------------------
+// the numerical gate
+constexpr int kPwSampleRows = 1024;
+
+__host__ __device__ inline long long pw_sample_row(int s, int S, long long pixels) {
+    if (pixels <= S) return s;
+    if (s < 128) return s;
+    if (s >= S - 512) return pixels - (S - s);
+    const unsigned long long hsh = (unsigned long long)(s - 127) * 0x9E3779B97F4A7C15ull;
+    return 128 + (long long)((hsh >> 20) % (unsigned long long)(pixels - 640));
+}
+
+template <typename T>
+__device__ inline float pw_ld(const T* p, long long i) { return (float)p[i]; }
+
+// ref[s][co], tol[s][co] for the sampled rows; one block per sampled row
+template <typename T>
+__global__ __launch_bounds__(256) void pw_ref_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ bias,
+                                                     const T* __restrict__ res, float* __restrict__ ref, float* __restrict__ tol,
+                                                     long long pixels, int cin, int cout, int relu, int S, float eps_out) {
+    extern __shared__ float xs[];
+    const int s = blockIdx.x;
+    const long long row = pw_sample_row(s, S, pixels);
+    for (int i = threadIdx.x; i < cin; i += blockDim.x) xs[i] = pw_ld(x, row * cin + i);
+    __syncthreads();
+    for (int co = threadIdx.x; co < cout; co += blockDim.x) {
+        const T* wr = w + (long long)co * cin;
+        float acc = 0.0f, mag = 0.0f;
+        for (int i = 0; i < cin; ++i) {
+            const float wv = (float)wr[i];
+            acc = fmaf(xs[i], wv, acc);
+            mag = fmaf(fabsf(xs[i]), fabsf(wv), mag);
+        }
+        if (bias) { const float b = (float)bias[co]; acc += b; mag += fabsf(b); }
+        if (res) { const float r = pw_ld(res, row * cout + co); acc += r; mag += fabsf(r); }
+        if (relu) acc = acc > 0.0f ? acc : 0.0f;
+        ref[(long long)s * cout + co] = acc;
+        tol[(long long)s * cout + co] = eps_out * fabsf(acc) + 3.8146973e-6f * mag + 1e-30f;
+    }
+}
+
+// worst |y - ref| / tol over the sampled rows -> *worst (float bits, non-negative: unsigned order = float order)
+template <typename T>
+__global__ __launch_bounds__(256) void pw_cmp_kernel(const T* __restrict__ y, const float* __restrict__ ref,
+                                                     const float* __restrict__ tol, long long pixels, int cout, int S,
+                                                     unsigned* __restrict__ worst) {
+    const int s = blockIdx.x;
+    const long long row = pw_sample_row(s, S, pixels);
+    float m = 0.0f;
+    for (int co = threadIdx.x; co < cout; co += blockDim.x) {
+        const long long k = (long long)s * cout + co;
+        float r = fabsf(pw_ld(y, row * cout + co) - ref[k]) / tol[k];
+        if (!(r <= 3.0e38f)) r = 3.0e38f;   // NaN / inf
+        m = fmaxf(m, r);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(worst, __float_as_uint(m));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct PwPlan {
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t lw = nullptr, lx = nullptr, ly = nullptr;
     hipblasLtMatmulAlgo_t algo;
     size_t ws = 0;
-    bool tuned = false;      // algo was timed on this exact problem
-    bool ok = false;
+    void* ws_buf = nullptr;  // this plan's own workspace (zeroed once): no other algorithm writes here
+    bool ok = false;         // algo is validated (and timed, or taken from the cache and re-validated) on this exact problem
+    bool dead = false;       // no candidate passed the gate: always "unsupported"
 };
 
 struct PwDevice {
     hipblasLtHandle_t handle = nullptr;
-    void* workspace = nullptr;
+    void* workspace = nullptr;   // tuning workspace (candidates run here one after the other, zeroed before each)
     size_t ws_bytes = 0;
-    std::string ident;     // device name + library version, for the rank cache key
+    float *ref = nullptr, *tol = nullptr;   // gate buffers, grown on demand
+    size_t gate_elems = 0;
+    unsigned* worst = nullptr;
+    std::string ident;     // device name + library version, for the cache key
     // (pixels, cin, cout, dtype, epilogue, residual) -> plan
     std::map<std::tuple<long long, int, int, int, int, int>, PwPlan> plans;
 };
@@ -45,19 +129,17 @@ struct PwDevice {
 inline std::mutex& pw_mutex() { static std::mutex m; return m; }
 inline std::map<int, PwDevice>& pw_devices() { static std::map<int, PwDevice> d; return d; }
 
-// Which of the library's ranked candidates won the timing, per exact problem, remembered across processes: the next process asks
-// the library for the same ranked list (milliseconds) and takes the remembered rank instead of timing 48 candidates again (~0.5 s,
-// a fifth of a DAVIS-sized job).  The algorithm itself is always a fresh answer of the library for the exact problem; the key holds
-// the device name and the library version, so another stack simply searches again.  One text line per entry, appended with a single
-// write (safe with one process per GPU).  $VOSPROP_CACHE_DIR or ~/.cache/vosprop; VOSPROP_PW_CACHE=0 turns it off.
-struct PwRankCache {
+// The validated winner's library solution index, per exact problem, remembered across processes ($VOSPROP_CACHE_DIR or
+// ~/.cache/vosprop; VOSPROP_PW_CACHE=0 turns it off).  One text line per entry, appended with a single write (safe with one
+// process per GPU).  An entry is a hint only: it is re-validated before use.
+struct PwAlgoCache {
     bool loaded = false, enabled = true;
     std::string file;
-    std::map<std::string, int> rank;
+    std::map<std::string, int> index;
 };
-inline PwRankCache& pw_rank_cache() { static PwRankCache c; return c; }
+inline PwAlgoCache& pw_algo_cache() { static PwAlgoCache c; return c; }
 
-inline void pw_rank_cache_load(PwRankCache& c) {
+inline void pw_algo_cache_load(PwAlgoCache& c) {
     c.loaded = true;
     const char* off = getenv("VOSPROP_PW_CACHE");
     if (off && off[0] == '0') { c.enabled = false; return; }
@@ -69,19 +151,19 @@ inline void pw_rank_cache_load(PwRankCache& c) {
         dir += "/vosprop";
     } else { c.enabled = false; return; }
     (void)mkdir(dir.c_str(), 0755);
-    c.file = dir + "/pointwise_ranks_v1.txt";
+    c.file = dir + "/pointwise_algos_v2.txt";
     if (FILE* f = fopen(c.file.c_str(), "r")) {
         char key[512];
         int r;
-        while (fscanf(f, "%511s %d", key, &r) == 2) c.rank[key] = r;
+        while (fscanf(f, "%511s %d", key, &r) == 2) c.index[key] = r;
         fclose(f);
     }
 }
 
-inline void pw_rank_cache_store(PwRankCache& c, const std::string& key, int r) {
-    if (!c.enabled || c.file.empty()) return;
-    c.rank[key] = r;
-    const std::string line = key + " " + std::to_string(r) + "\n";
+inline void pw_algo_cache_store(PwAlgoCache& c, const std::string& key, int idx) {
+    if (!c.enabled || c.file.empty() || idx < 0) return;
+    c.index[key] = idx;
+    const std::string line = key + " " + std::to_string(idx) + "\n";
     const int fd = open(c.file.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
     if (fd < 0) return;
     (void)!write(fd, line.data(), line.size());
@@ -104,10 +186,85 @@ inline int pw_candidates() {      // VOSPROP_PW_CANDIDATES: how many of the libr
     }();
     return n;
 }
+inline bool pw_verbose() { static const bool v = getenv("VOSPROP_PW_VERBOSE") != nullptr; return v; }
 
-// returns 0 on success, 1 = invalid argument, 2 = library / HIP failure, 3 = no algorithm for this shape
+inline float pw_eps_out(int dtype_key) {   // two roundings of the output type (VOSPROP_DT_*: 0 f32, 1 f16, 2 bf16)
+    return dtype_key == 2 ? 0.0078125f : dtype_key == 1 ? 0.0009765625f : 4.76837158e-7f;
+}
+
+// One problem, fully described (operands of THIS call)
+struct PwCall {
+    const void *x, *w, *bias, *residual;
+    void* y;
+    long long pixels;
+    int cin, cout, relu, dtype_key;
+    hipStream_t s;
+};
+
+inline int pw_gate_rows(long long pixels) { return (int)(pixels < kPwSampleRows ? pixels : kPwSampleRows); }
+
+// reference + tolerances of the sampled rows from the operands as they are NOW (before any candidate has written y)
+inline bool pw_gate_prepare(PwDevice& D, const PwCall& c) {
+    const int S = pw_gate_rows(c.pixels);
+    const size_t need = (size_t)S * c.cout;
+    if (need > D.gate_elems) {
+        if (D.ref) (void)hipFree(D.ref);
+        if (D.tol) (void)hipFree(D.tol);
+        D.ref = D.tol = nullptr;
+        D.gate_elems = 0;
+        if (hipMalloc((void**)&D.ref, need * 4) != hipSuccess || hipMalloc((void**)&D.tol, need * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        D.gate_elems = need;
+    }
+    if (!D.worst && hipMalloc((void**)&D.worst, 4) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const float eps = pw_eps_out(c.dtype_key);
+    const size_t sh = (size_t)c.cin * 4;
+#define VOSPROP_PW_REF(T)                                                                                                        \
+    hipLaunchKernelGGL(pw_ref_kernel<T>, dim3(S), dim3(256), sh, c.s, (const T*)c.x, (const T*)c.w, (const T*)c.bias,           \
+                       (const T*)c.residual, D.ref, D.tol, c.pixels, c.cin, c.cout, c.relu, S, eps)
+    if (c.dtype_key == 2) VOSPROP_PW_REF(bf16_t);
+    else if (c.dtype_key == 1) VOSPROP_PW_REF(_Float16);
+    else VOSPROP_PW_REF(float);
+#undef VOSPROP_PW_REF
+    return hipGetLastError() == hipSuccess;
+}
+
+// worst |y - ref| / tol of what is in `y` now; < 0 on failure.  Synchronises the stream.
+inline float pw_gate_check(PwDevice& D, const PwCall& c, const void* y) {
+    const int S = pw_gate_rows(c.pixels);
+    if (hipMemsetAsync(D.worst, 0, 4, c.s) != hipSuccess) { (void)hipGetLastError(); return -1.0f; }
+#define VOSPROP_PW_CMP(T) \
+    hipLaunchKernelGGL(pw_cmp_kernel<T>, dim3(S), dim3(256), 0, c.s, (const T*)y, D.ref, D.tol, c.pixels, c.cout, S, D.worst)
+    if (c.dtype_key == 2) VOSPROP_PW_CMP(bf16_t);
+    else if (c.dtype_key == 1) VOSPROP_PW_CMP(_Float16);
+    else VOSPROP_PW_CMP(float);
+#undef VOSPROP_PW_CMP
+    unsigned bits = 0;
+    if (hipMemcpyAsync(&bits, D.worst, 4, hipMemcpyDeviceToHost, c.s) != hipSuccess || hipStreamSynchronize(c.s) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0f;
+    }
+    union { unsigned u; float f; } v;
+    v.u = bits;
+    return v.f;
+}
+
+struct PwCandidateReport {   // vosprop_debug_pointwise_candidates (tests): one row per candidate the library returned
+    int index;               // library solution index
+    int workspace;           // bytes
+    float us;                // timed launch, microseconds (< 0: launch failed)
+    float worst_clean;       // worst |err| / tol on a zeroed workspace (after warm + timed launches)
+    float worst_dirty;       // the same with the workspace filled with 0xFF before the launches (what sharing one workspace
+                             // between algorithms can leave behind)
+    char name[160];
+};
+
+// returns 0 on success, 1 = invalid argument, 2 = library / HIP failure, 3 = no (validated) algorithm for this shape
 inline int pointwise_conv(const void* x, const void* w, const void* bias, const void* residual, void* y, long long pixels,
-                          int cin, int cout, int relu, hipDataType dt, int dtype_key, hipStream_t s) {
+                          int cin, int cout, int relu, hipDataType dt, int dtype_key, hipStream_t s,
+                          PwCandidateReport* report = nullptr, int report_cap = 0, int* report_n = nullptr) {
     if (!x || !w || !y || pixels < 0 || cin <= 0 || cout <= 0) return 1;
     if (pixels == 0) return 0;
     hipPointerAttribute_t at;
@@ -134,12 +291,14 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
             if (ch == ' ' || ch == '\t' || ch == '\n') ch = '_';
         D.ident += ":lt" + std::to_string(ver);
     }
-    if (!D.workspace && !capturing) {
-        if (hipMalloc(&D.workspace, kPwWorkspace) == hipSuccess) D.ws_bytes = kPwWorkspace;
-        else { (void)hipGetLastError(); D.workspace = nullptr; }
-    }
     const int ep_key = (bias ? 1 : 0) | (relu ? 2 : 0);
     PwPlan& P = D.plans[std::make_tuple(pixels, cin, cout, dtype_key, ep_key, residual ? 1 : 0)];
+    if (P.dead && !report) return 3;
+    if (!P.ok && capturing) return 3;   // nothing is tuned or validated inside a capture: the caller takes the convolution path
+    if (!D.workspace) {
+        if (hipMalloc(&D.workspace, kPwWorkspace) == hipSuccess) D.ws_bytes = kPwWorkspace;
+        else { (void)hipGetLastError(); D.workspace = nullptr; D.ws_bytes = 0; }
+    }
     if (!P.desc) {
         if (hipblasLtMatmulDescCreate(&P.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return 2;
         const hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
@@ -161,86 +320,156 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
     }
     if (bias) hipblasLtMatmulDescSetAttribute(P.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
     const float alpha = 1.f, beta = residual ? 1.f : 0.f;
-    const void* C = residual ? residual : y;
 
-    auto run = [&](const hipblasLtMatmulAlgo_t& algo, size_t ws) {
-        return hipblasLtMatmul(D.handle, P.desc, &alpha, w, P.lw, x, P.lx, &beta, C, P.ly, y, P.ly, &algo,
-                               ws ? D.workspace : nullptr, ws, s);
+    // out: where the product is written; C operand: the residual, or `out` itself (beta = 0: never read)
+    auto run = [&](hipblasLtMatmulAlgo_t& algo, size_t ws, void* ws_buf, void* out) {
+        const void* C = residual ? residual : out;
+        return hipblasLtMatmul(D.handle, P.desc, &alpha, w, P.lw, x, P.lx, &beta, C, P.ly, out, P.ly, &algo, ws ? ws_buf : nullptr,
+                               ws, s);
     };
 
-    if (!P.ok || (!P.tuned && !capturing && residual != y)) {
-        hipblasLtMatmulPreference_t pref = nullptr;
-        if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return 2;
-        const uint64_t max_ws = D.ws_bytes;
-        hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws));
-        const int want = pw_candidates();
-        std::vector<hipblasLtMatmulHeuristicResult_t> res(want);
-        int got = 0;
-        const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(D.handle, P.desc, P.lw, P.lx, P.ly, P.ly, pref, want,
-                                                                   res.data(), &got);
-        hipblasLtMatmulPreferenceDestroy(pref);
-        if (hs != HIPBLAS_STATUS_SUCCESS || got <= 0) return 3;
-        int best = -1;
-        PwRankCache& RC = pw_rank_cache();
-        if (!RC.loaded) pw_rank_cache_load(RC);
-        const std::string ckey = D.ident + "|" + std::to_string(pixels) + "|" + std::to_string(cin) + "|" + std::to_string(cout) + "|" +
-                                 std::to_string(dtype_key) + "|" + std::to_string(ep_key) + "|" + (residual ? "r" : "-") + "|" +
-                                 std::to_string(want);
-        int cached_rank = -1;
-        if (RC.enabled) {
-            auto it = RC.rank.find(ckey);
-            if (it != RC.rank.end()) cached_rank = it->second;
+    if (!P.ok || report) {
+        // ---- first call for this exact problem (never inside a capture): gate + timing -------------------------------------
+        const PwCall call{x, w, bias, residual, y, pixels, cin, cout, relu, dtype_key, s};
+        // a tuning launch must not accumulate into its own input: when the residual aliases y, candidates write to a scratch copy
+        void* out = y;
+        void* scratch = nullptr;
+        const size_t esz = dtype_key == 0 ? 4 : 2;
+        if (residual == y) {
+            if (hipMalloc(&scratch, (size_t)pixels * cout * esz) != hipSuccess) { (void)hipGetLastError(); return 2; }
+            out = scratch;
         }
-        if (capturing || residual == y) {
-            // no timing inside a capture (or when a timing run would accumulate into its own input): first candidate that fits
-            for (int i = 0; i < got && best < 0; ++i)
-                if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= D.ws_bytes) best = i;
-        } else if (cached_rank >= 0 && cached_rank < got && res[cached_rank].state == HIPBLAS_STATUS_SUCCESS &&
-                   res[cached_rank].workspaceSize <= D.ws_bytes) {
-            best = cached_rank;      // timed by an earlier process on this stack
-            P.tuned = true;
-            if (getenv("VOSPROP_PW_VERBOSE"))
-                fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d: rank #%d from %s\n", pixels, cin, cout, best, RC.file.c_str());
-        } else {
-            // the library's ranking is a model (the winners measured on MI355X sit at ranks 2-43): time its candidates once on
-            // the real operands - the output is simply rewritten
-            hipEvent_t e0, e1;
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 2;
-            float best_ms = 1e30f;
-            // one timed launch per candidate after a warm one (which also loads its code object); only candidates within 15 %
-            // of the best so far get a 3-launch measurement - the search costs ~2 launches per candidate instead of 4
-            auto timed = [&](int i, int reps, float* ms) {
-                (void)hipEventRecord(e0, s);
-                bool fine = true;
-                for (int r = 0; r < reps && fine; ++r) fine = run(res[i].algo, res[i].workspaceSize) == HIPBLAS_STATUS_SUCCESS;
-                (void)hipEventRecord(e1, s);
-                if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); fine = false; }
-                if (!fine || hipEventElapsedTime(ms, e0, e1) != hipSuccess) return false;
-                *ms /= (float)reps;
-                return true;
-            };
+        struct FreeScratch { void* p; ~FreeScratch() { if (p) (void)hipFree(p); } } free_scratch{scratch};
+        if (!pw_gate_prepare(D, call)) return 2;
+
+        PwAlgoCache& AC = pw_algo_cache();
+        if (!AC.loaded) pw_algo_cache_load(AC);
+        const int want = pw_candidates();
+        const std::string ckey = D.ident + "|" + std::to_string(pixels) + "|" + std::to_string(cin) + "|" + std::to_string(cout) + "|" +
+                                 std::to_string(dtype_key) + "|" + std::to_string(ep_key) + "|" + (residual ? "r" : "-") + "|ws" +
+                                 std::to_string(D.ws_bytes);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 2;
+        struct FreeEvents { hipEvent_t a, b; ~FreeEvents() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } fe{e0, e1};
+        auto timed = [&](hipblasLtMatmulAlgo_t& algo, size_t ws, int reps, float* ms) {
+            (void)hipEventRecord(e0, s);
+            bool fine = true;
+            for (int r = 0; r < reps && fine; ++r) fine = run(algo, ws, D.workspace, out) == HIPBLAS_STATUS_SUCCESS;
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); fine = false; }
+            if (!fine || hipEventElapsedTime(ms, e0, e1) != hipSuccess) return false;
+            *ms /= (float)reps;
+            return true;
+        };
+        // candidate on the tuning workspace filled with `fill`: warm launch, timed launch(es), gate on the LAST output
+        auto trial = [&](hipblasLtMatmulAlgo_t& algo, size_t ws, int fill, float best_ms, float* ms, float* worst) {
+            *worst = -1.0f;
+            if (ws > D.ws_bytes) return false;
+            if (ws && hipMemsetAsync(D.workspace, fill, ws, s) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (run(algo, ws, D.workspace, out) != HIPBLAS_STATUS_SUCCESS) return false;   // warm (also loads the code object)
+            if (!timed(algo, ws, 1, ms)) return false;
+            if (*ms <= 1.15f * best_ms && !timed(algo, ws, 3, ms)) return false;          // contenders get a 3-launch figure
+            *worst = pw_gate_check(D, call, out);
+            return *worst >= 0.0f;
+        };
+
+        int best_index = -1;
+        bool have = false;
+        hipblasLtMatmulAlgo_t best_algo;
+        size_t best_ws = 0;
+        float best_ms = 1e30f;
+        // ---- a remembered algorithm: ask the library whether it still serves this problem, then re-validate it ----
+        if (!report && AC.enabled) {
+            auto it = AC.index.find(ckey);
+            if (it != AC.index.end()) {
+                std::vector<int> idx{it->second};
+                std::vector<hipblasLtMatmulHeuristicResult_t> got;
+                if (hipblaslt_ext::getAlgosFromIndex(D.handle, idx, got) == HIPBLAS_STATUS_SUCCESS && !got.empty()) {
+                    size_t ws = 0;
+                    if (hipblaslt_ext::matmulIsAlgoSupported(D.handle, P.desc, &alpha, P.lw, P.lx, &beta, P.ly, P.ly, got[0].algo, ws) ==
+                            HIPBLAS_STATUS_SUCCESS && ws <= D.ws_bytes) {
+                        float ms = 0.f, worst = -1.f;
+                        if (trial(got[0].algo, ws, 0, 0.0f, &ms, &worst) && worst <= 1.0f) {
+                            have = true;
+                            best_algo = got[0].algo;
+                            best_ws = ws;
+                            best_index = it->second;
+                            best_ms = ms;
+                            if (pw_verbose())
+                                fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d: cached algo %d re-validated (worst err/tol %.3f) from %s\n",
+                                        pixels, cin, cout, best_index, worst, AC.file.c_str());
+                        } else if (pw_verbose()) {
+                            fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d: cached algo %d REJECTED (worst err/tol %.3g)\n", pixels, cin,
+                                    cout, it->second, worst);
+                        }
+                    }
+                }
+            }
+        }
+        if (!have) {
+            hipblasLtMatmulPreference_t pref = nullptr;
+            if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return 2;
+            const uint64_t max_ws = D.ws_bytes;
+            hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &max_ws, sizeof(max_ws));
+            std::vector<hipblasLtMatmulHeuristicResult_t> res(want);
+            int got = 0;
+            const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(D.handle, P.desc, P.lw, P.lx, P.ly, P.ly, pref, want,
+                                                                       res.data(), &got);
+            hipblasLtMatmulPreferenceDestroy(pref);
+            if (hs != HIPBLAS_STATUS_SUCCESS || got <= 0) { P.dead = true; return 3; }
+            // the library's ranking is a model (the winners measured on MI355X sit at ranks 2-43): time its candidates once on the
+            // real operands - and let only those whose output passes the gate compete
+            int n_rejected = 0;
+            if (report_n) *report_n = 0;
             for (int i = 0; i < got; ++i) {
                 if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > D.ws_bytes) continue;
-                if (run(res[i].algo, res[i].workspaceSize) != HIPBLAS_STATUS_SUCCESS) continue;   // warm
-                float ms = 0.f;
-                if (!timed(i, 1, &ms) || ms > 1.15f * best_ms) continue;
-                if (!timed(i, 3, &ms)) continue;
-                if (ms < best_ms) { best_ms = ms; best = i; }
+                float ms = 0.f, worst = -1.f;
+                const bool ran = trial(res[i].algo, res[i].workspaceSize, 0, report ? 0.0f : best_ms, &ms, &worst);
+                if (report && report_n && *report_n < report_cap) {
+                    PwCandidateReport& R = report[(*report_n)++];
+                    R.index = hipblaslt_ext::getIndexFromAlgo(res[i].algo);
+                    R.workspace = (int)res[i].workspaceSize;
+                    R.us = ran ? ms * 1e3f : -1.0f;
+                    R.worst_clean = worst;
+                    float ms2 = 0.f, worst2 = -1.f;
+                    (void)trial(res[i].algo, res[i].workspaceSize, 0xFF, 0.0f, &ms2, &worst2);
+                    R.worst_dirty = worst2;
+                    const std::string nm = hipblaslt_ext::getSolutionNameFromAlgo(D.handle, res[i].algo);
+                    snprintf(R.name, sizeof(R.name), "%s", nm.c_str());
+                }
+                if (!ran) continue;
+                if (!(worst <= 1.0f)) {
+                    ++n_rejected;
+                    if (pw_verbose())
+                        fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d: candidate #%d (algo %d, ws %zu) REJECTED by the gate: worst err/tol %.3g\n",
+                                pixels, cin, cout, i, hipblaslt_ext::getIndexFromAlgo(res[i].algo), (size_t)res[i].workspaceSize, worst);
+                    continue;
+                }
+                if (ms < best_ms) {
+                    best_ms = ms;
+                    best_algo = res[i].algo;
+                    best_ws = res[i].workspaceSize;
+                    best_index = hipblaslt_ext::getIndexFromAlgo(res[i].algo);
+                    have = true;
+                }
             }
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-            P.tuned = best >= 0;
-            if (best >= 0) pw_rank_cache_store(RC, ckey, best);
-            if (getenv("VOSPROP_PW_VERBOSE"))
-                fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d (bias %d relu %d residual %d): %d candidates, #%d wins, %.1f us\n",
-                        pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, best, best_ms * 1e3f);
+            if (pw_verbose())
+                fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d (bias %d relu %d residual %d): %d candidates, %d rejected by the gate, algo %d wins, %.1f us\n",
+                        pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, n_rejected, best_index, best_ms * 1e3f);
+            if (report) return 0;
+            if (!have) { P.dead = true; return 3; }
+            pw_algo_cache_store(AC, ckey, best_index);
         }
-        if (best < 0) return 3;
-        P.algo = res[best].algo;
-        P.ws = res[best].workspaceSize;
+        // the winner's own workspace, zeroed once (stream-ordered before its first launch)
+        if (best_ws) {
+            if (hipMalloc(&P.ws_buf, best_ws) != hipSuccess) { (void)hipGetLastError(); P.ws_buf = nullptr; return 2; }
+            if (hipMemsetAsync(P.ws_buf, 0, best_ws, s) != hipSuccess) { (void)hipGetLastError(); return 2; }
+        }
+        P.algo = best_algo;
+        P.ws = best_ws;
         P.ok = true;
     }
-    return run(P.algo, P.ws) == HIPBLAS_STATUS_SUCCESS ? 0 : 2;
+    return run(P.algo, P.ws, P.ws_buf, y) == HIPBLAS_STATUS_SUCCESS ? 0 : 2;
 }
 
 }  // namespace vosprop

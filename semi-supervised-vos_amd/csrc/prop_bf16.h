@@ -61,7 +61,6 @@ constexpr int kOffCoord = kLdsFeat;
 constexpr int kOffLabHi = kLdsFeat + kLdsCoord;
 constexpr int kOffLabLo = kOffLabHi + kLdsLab;
 constexpr int kLdsBuf = kOffLabLo + kLdsLab;      // 22528
-constexpr int kRing = 3;                          // v5 kernel
 constexpr int kRing4 = 4;                         // shipped kernel: tiles are staged THREE steps ahead (see the main loop)
 constexpr int kGlbFeat = kTileR * kC * 2;         // 16384 bytes of one tile in HBM
 constexpr float kRescaleThr = 8.0f;               // defer-max threshold in log2 units (p <= 2^8)

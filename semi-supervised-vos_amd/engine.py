@@ -186,6 +186,8 @@ class PropagationEngine:
 
 def sample_frames_list(frame_idx, take_range, num_refs):
     """reference sample_frames (src/model/predict.py:74-89) through the C ABI (host-side, exact)."""
-    buf = (ctypes.c_int * max(int(num_refs), int(frame_idx), 1))()
+    buf = (ctypes.c_int * (max(int(num_refs), int(frame_idx), 1) + 4))()
     n = _native.lib().vosprop_sample_frames(int(frame_idx), int(take_range), int(num_refs), buf)
+    if n < 0:     # num_refs < 3 past frame num_refs: the reference's np.linspace(.., num < 0) raises ValueError
+        raise ValueError(f'Number of samples, {int(num_refs) - 3}, must be non-negative.')
     return [buf[i] for i in range(n)]

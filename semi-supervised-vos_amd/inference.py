@@ -52,8 +52,8 @@ _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
 @click.option('--fusion', default='mean', type=click.Choice(['maximum', 'minimum', 'mean']),
               help='Fusion operation for probability propagation.')
 @click.option('--gpus', type=int, default=1, help='[engine] GPUs of this node to shard the videos over.')
-@click.option('--encoder-dtype', type=click.Choice(sorted(_DTYPES)), default='bf16',
-              help='[engine] encoder precision (the reference runs it under fp16 autocast on GPU).')
+@click.option('--encoder-dtype', type=click.Choice(sorted(_DTYPES)), default='f16',
+              help='[engine] encoder precision (default f16: the reference runs it under fp16 autocast on GPU).')
 @click.option('--encoder-batch', type=int, default=32, help='[engine] frames per encoder call (look-ahead).')
 @click.option('--io-workers', type=int, default=None,
               help='[engine] JPEG decode processes (default: min(8, cores - 1); the reference uses 1).')
@@ -75,14 +75,27 @@ def inference_command(ref_num, data, resume, model, temperature, frame_range, si
                            png_workers=png_workers, encoder_graph=encoder_graph, miopen_find=miopen_find)
 
 
+def visible_devices(n):
+    """Device ordinals (as strings for HIP_VISIBLE_DEVICES) of the first n GPUs this process is allowed to use: the entries of
+    an inherited HIP_VISIBLE_DEVICES / ROCR-style list when one is set, else 0..n-1."""
+    inherited = [d.strip() for d in os.environ.get('HIP_VISIBLE_DEVICES', '').split(',') if d.strip() != '']
+    if inherited:
+        if len(inherited) < n:
+            raise SystemExit(f'--gpus {n} but HIP_VISIBLE_DEVICES={os.environ["HIP_VISIBLE_DEVICES"]} lists {len(inherited)}')
+        return inherited[:n]
+    return [str(i) for i in range(n)]
+
+
 def _launch_shards(gpus):
     """One child process per GPU (HIP_VISIBLE_DEVICES pins it); children never exec after touching the GPU."""
     argv = [a for a in sys.argv[1:]]
     procs = []
     # VOSPROP_SHARD_DEVICES="0,0": device ordinal per shard (testing the sharded path on a box with fewer GPUs than shards)
     devs = [d for d in os.environ.get('VOSPROP_SHARD_DEVICES', '').split(',') if d != '']
+    if not devs:      # shard r -> the r-th device THIS process may see: an inherited HIP_VISIBLE_DEVICES is a list to index into
+        devs = visible_devices(gpus)
     for r in range(gpus):
-        env = dict(os.environ, HIP_VISIBLE_DEVICES=devs[r % len(devs)] if devs else str(r), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=devs[r % len(devs)], HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, sys.argv[0]] + argv + ['--shard', str(r), str(gpus)], env=env,
                                       stdout=subprocess.PIPE, text=True))
     frames, secs, rc = 0, 0.0, 0
@@ -101,7 +114,7 @@ def _launch_shards(gpus):
 
 def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
-                           reduction, disable=False, encoder_dtype='bf16', shard=(0, 1), encoder_batch=32, io_workers=None,
+                           reduction, disable=False, encoder_dtype='f16', shard=(0, 1), encoder_batch=32, io_workers=None,
                            png_workers=2, encoder_graph=True, miopen_find=False):
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)

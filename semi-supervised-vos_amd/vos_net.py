@@ -326,9 +326,13 @@ class GraphedEncoder:
                 return self.net(x)
             try:
                 self._capture(x)
-            except Exception:              # capture is an optimisation: never a reason to fail the run
+            except Exception as e:         # capture is an optimisation: never a reason to fail the run - but never silent
                 self.failed = True
                 torch.cuda.synchronize()
+                import sys
+                print(f'[vosprop] HIP-graph capture of the encoder failed for input {tuple(x.shape)} {x.dtype} '
+                      f'({type(e).__name__}: {e}); running it eagerly from here on (~2x more host time per batch)',
+                      file=sys.stderr, flush=True)
                 return self.net(x)
         g, xs, ys = self.graphs[key]
         xs.copy_(x)

@@ -1,5 +1,7 @@
 import importlib
+import os
 import sys
+import tempfile
 from pathlib import Path
 
 import pytest
@@ -10,8 +12,28 @@ if str(ROOT) not in sys.path:
 sys.path.insert(0, str(ROOT / 'tests' / 'golden'))
 
 
+# The suite never reads or writes the user's ~/.cache: the pointwise-GEMM algorithm cache (csrc/pointwise.h) of this session
+# lives in a fresh temporary directory, so what a test computes does not depend on the machine's history.
+os.environ['VOSPROP_CACHE_DIR'] = tempfile.mkdtemp(prefix='vosprop_test_cache_')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+# Order of the files under `-x`: the hot path first (operator parity, roll-outs, CLI, strategies,
+# look-ahead), then the rows either side of it (encoder, host pipeline).  A failure in a "next" row can then never hide the
+# evidence for the path itself (which is what happened to the round-1 driver run).
+_FILE_ORDER = ['test_oracle_golden.py', 'test_gpu_parity.py', 'test_gpu_precision.py', 'test_gpu_configs.py', 'test_gpu_cli.py',
+               'test_gpu_strategies.py', 'test_gpu_lookahead.py', 'test_host.py', 'test_metrics.py', 'test_bench_launcher.py',
+               'test_encoder.py']
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = Path(str(item.fspath)).name
+        return _FILE_ORDER.index(name) if name in _FILE_ORDER else len(_FILE_ORDER) - 1
+    items.sort(key=key)          # stable: the order inside a file is kept
 
 
 @pytest.fixture(scope='session', autouse=True)

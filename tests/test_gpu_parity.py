@@ -185,6 +185,42 @@ def test_state_errors(vos, dev):
     eng.close()
 
 
+def test_fewer_references_than_continuous_frames(vos, dev):
+    """ref_num = 3 past frame 3 samples the three continuous frames alone (numpy's empty linspace); ref_num < 3 past frame ref_num
+    is an error in the reference (np.linspace with a negative count) and VOSPROP_E_INVALID here - never an out-of-bounds write
+    into a scratch ring sized by ref_num (round-1 advisor finding); a ring smaller than the sampling window is refused."""
+    Hd, Wd, T, d = 6, 9, 12, 3
+    feats, oh = _random_case(31, Hd, Wd, T, d)
+    wd, ws = vo.get_spatial_weight((Hd, Wd), 8.0), vo.get_spatial_weight((Hd, Wd), 21.0)
+    fd, ld = torch.from_numpy(feats).to(dev), torch.from_numpy(oh).to(dev)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=3, frame_range=4)
+    for fi in (2, 3, 4, 11):
+        got = eng.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 4, 3, 1.0, 8.0, 21.0, False).cpu().numpy()
+        want = vo.predict(feats[:fi], feats[fi], oh[:, :fi], wd, ws, fi, 4, 3, 1.0, False).numpy()
+        check_close(got, want, rel=4e-3)
+    for nref in (1, 2):
+        fi = nref        # every previous frame: fine
+        got = eng.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 4, nref, 1.0, 8.0, 21.0, False).cpu().numpy()
+        want = vo.predict(feats[:fi], feats[fi], oh[:, :fi], wd, ws, fi, 4, nref, 1.0, False).numpy()
+        check_close(got, want, rel=4e-3)
+        with pytest.raises(vos.VospropError):
+            eng.predict(fd[:5], fd[5], ld[:, :5], 5, 4, nref, 1.0, 8.0, 21.0, False)
+    eng.close()
+    # the stateful path: ref_num = 2 works for frames 1, 2 and reports the reference's error at frame 3
+    e2 = vos.PropagationEngine(Hd, Wd, device=0, ref_num=2, frame_range=4)
+    ann = np.zeros((Hd * 8, Wd * 8), np.uint8)
+    ann[: Hd * 4] = 1
+    e2.begin_video(ann)
+    for t in range(3):
+        e2.step(fd[t])
+    with pytest.raises(vos.VospropError):
+        e2.step(fd[3])
+    e2.close()
+    with pytest.raises(vos.VospropError):
+        vos.PropagationEngine(Hd, Wd, device=0, ref_num=9, frame_range=40, ring_capacity=10)     # needs 45 slots
+    vos.PropagationEngine(Hd, Wd, device=0, ref_num=9, frame_range=40, ring_capacity=45).close()
+
+
 # ---- top-k variant (SURVEY.md section 8a row A9): not in the reference; checked against the oracle's restatement and
 # ---- through the identity  k >= N*HW  ==  dense ------------------------------------------------------------------
 @pytest.mark.parametrize('Hd,Wd,T,d,fi,k', [

@@ -45,6 +45,23 @@ def test_sample_frames_through_the_abi(vos, goldens, rng, nref):
         assert vos.sample_frames_list(fi, rng, nref) == [int(v) for v in g[fi - 1] if v >= 0]
 
 
+def test_sample_frames_with_fewer_than_three_references(vos):
+    """ref_num < CONTINUOUS_FRAME - 1: past frame ref_num the reference asks np.linspace for a negative number of samples and
+    raises ValueError (src/model/predict.py:80-85) - the ABI reports VOSPROP_E_INVALID there instead of returning 3 indices for
+    a 2-slot ring (round-1 advisor finding); ref_num == 3 gives the three continuous frames alone, as numpy's empty linspace does."""
+    from oracle import vos_oracle as vo
+    for nref in (1, 2):
+        for fi in range(1, nref + 1):
+            assert vos.sample_frames_list(fi, 40, nref) == vo.sample_frames(fi, 40, nref) == list(range(fi))
+        for fi in (nref + 1, nref + 5, 30):
+            with pytest.raises(ValueError):
+                vo.sample_frames(fi, 40, nref)
+            with pytest.raises(ValueError):
+                vos.sample_frames_list(fi, 40, nref)
+    for fi in (4, 9, 57):
+        assert vos.sample_frames_list(fi, 40, 3) == vo.sample_frames(fi, 40, 3) == [fi - 3, fi - 2, fi - 1]
+
+
 def test_create_without_gpu_fails_loudly(vos):
     if torch.cuda.is_available():
         pytest.skip('GPU present')
