@@ -116,6 +116,53 @@ def predict(ref, target, ref_label, weight_dense, weight_sparse, frame_idx, take
     return lab_sel.float().mm(S.float())
 
 
+def spatial_weight_columns(shape, sigma, cols):
+    """Columns `cols` of get_spatial_weight(shape, sigma) without forming the (HW, HW) matrix (829 MB at 720p): the same
+    f32 operations on the same operands (predict.py:167-173), so the entries are bit-identical to slicing the full matrix."""
+    H, W = shape
+    index = torch.arange(H * W, dtype=torch.long).reshape(H * W, 1)
+    coords = torch.cat((index.div(float(W)), index % W), -1)        # (HW,2) f32
+    cols = torch.as_tensor(cols, dtype=torch.long)
+    diff = coords[cols].unsqueeze(0) - coords.unsqueeze(1)           # [p, j, :] = coords[cols[j]] - coords[p]  (as full[p, t])
+    d2 = diff.float().pow(2).sum(-1)
+    return (-d2 / sigma ** 2).exp()
+
+
+def predict_columns(ref, target, ref_label, sigma1, sigma2, frame_idx, take_range, ref_num, temperature,
+                    probability_propagation, cols, topk=0):
+    """`predict` restricted to the target pixels `cols`: returns predict(...)[:, cols].  Every target pixel is an independent
+    column of the reference's computation (mm column, softmax over dim 0, weight column, label mm column; predict.py:49-70), so
+    the full-size BASELINE configs (720p: a 7.5 GB f32 affinity, three times) can be checked on a few hundred columns in
+    seconds.  Same op order as `predict`; pinned to it by tests/test_oracle_golden.py::test_predict_columns_is_a_slice_of_predict."""
+    ref = torch.as_tensor(ref)
+    target = torch.as_tensor(target)
+    ref_label = torch.as_tensor(ref_label)
+    cols = torch.as_tensor(cols, dtype=torch.long)
+    d = ref_label.shape[0]
+    sample_idx = torch.tensor(sample_frames(frame_idx, take_range, ref_num), dtype=torch.long)
+    ref_sel = ref.index_select(0, sample_idx)
+    lab_sel = ref_label.index_select(1, sample_idx).reshape(d, -1)
+    num_ref, C, H, W = ref_sel.shape
+    R = ref_sel.permute(0, 2, 3, 1).reshape(-1, C)
+    T = target.reshape(C, -1)[:, cols].contiguous()
+    S = R.mm(T)
+    S *= temperature
+    S = S.softmax(dim=0)
+    S = S.contiguous().view(num_ref, H * W, cols.numel())
+    if not probability_propagation:
+        w_dense = spatial_weight_columns((H, W), sigma1, cols)
+        if frame_idx > 15:
+            S[:-CONTINUOUS_FRAME] *= spatial_weight_columns((H, W), sigma2, cols)
+            S[-CONTINUOUS_FRAME:] *= w_dense
+        else:
+            S = S.mul(w_dense)
+    S = S.view(-1, cols.numel())
+    if topk and topk < S.shape[0]:
+        kth = S.topk(topk, dim=0).values[-1:]
+        S = torch.where(S >= kth, S, torch.zeros_like(S))
+    return lab_sel.float().mm(S.float())
+
+
 class VideoState:
     """The per-video state `inference_single` keeps in module globals
     (src/utils/inference_utils.py:25,33-48)."""

@@ -16,8 +16,27 @@ template <> __device__ inline float to_f32<bf16_t>(bf16_t v) { return (float)v; 
 // grid = (ceil(HW/64), C/64), block = 256: one 64-pixel x 64-channel tile per block, transposed through LDS so that both
 // the reads (256 B runs along pixels) and the writes (16 B per lane along channels) are coalesced.
 // Rows >= HW of the slot stay zero (set once at allocation).
-template <typename T>
-__global__ __launch_bounds__(256) void push_kernel(const T* __restrict__ src, bf16_t* __restrict__ dst, int HW) {
+template <typename Out> struct Out8;
+template <> struct Out8<bf16_t> {
+    __device__ static inline void store(bf16_t* dst, const float (&v)[8]) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+        *(bf16x8*)dst = o;
+    }
+};
+template <> struct Out8<float> {      // the f32 ring of the parity path (VOSPROP_PREC_F32): values pass through unrounded
+    __device__ static inline void store(float* dst, const float (&v)[8]) {
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
+        *(f32x4*)dst = a;
+        *(f32x4*)(dst + 4) = b;
+    }
+};
+
+template <typename T, typename Out>
+__global__ __launch_bounds__(256) void push_kernel(const T* __restrict__ src, Out* __restrict__ dst, int HW) {
     __shared__ float tile[64][65];
     const int p0 = blockIdx.x * 64, cc = blockIdx.y * 64;
     const int tid = threadIdx.x;
@@ -35,23 +54,23 @@ __global__ __launch_bounds__(256) void push_kernel(const T* __restrict__ src, bf
         const int px = pass * 32 + (tid >> 3);
         const int c8 = (tid & 7) * 8;
         if (p0 + px < HW) {
-            bf16x8 o;
+            float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)tile[c8 + e][px];
-            *(bf16x8*)(dst + (size_t)(p0 + px) * kC + cc + c8) = o;
+            for (int e = 0; e < 8; ++e) o[e] = tile[c8 + e][px];
+            Out8<Out>::store(dst + (size_t)(p0 + px) * kC + cc + c8, o);
         }
     }
 }
 
 // Pixel-major (channels-last) source: (HW, C) rows are already in ring order, only the element type changes.
-template <typename T>
-__global__ __launch_bounds__(256) void push_hwc_kernel(const T* __restrict__ src, bf16_t* __restrict__ dst, int n8) {
+template <typename T, typename Out>
+__global__ __launch_bounds__(256) void push_hwc_kernel(const T* __restrict__ src, Out* __restrict__ dst, int n8) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
-    bf16x8 o;
+    float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)to_f32<T>(src[(size_t)i * 8 + e]);
-    *(bf16x8*)(dst + (size_t)i * 8) = o;
+    for (int e = 0; e < 8; ++e) o[e] = to_f32<T>(src[(size_t)i * 8 + e]);
+    Out8<Out>::store(dst + (size_t)i * 8, o);
 }
 
 // Element (s, lane, e) of a label tile is L[class = lane & 31][row = 16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)]:

@@ -63,7 +63,10 @@ struct Segment {
 
 // Per-launch description of one propagation (passed by value as a kernel argument).
 struct PropArgs {
-    const bf16_t* feat_ring;    // [cap][HWp][kC]        pixel-major bf16 features
+    const bf16_t* feat_ring;    // [cap][HWp][kC]        pixel-major bf16 features (VOSPROP_PREC_BF16)
+    const float* feat_f32;      // [cap][HWp][kC]        pixel-major f32 features (VOSPROP_PREC_F32; feat_ring is null then)
+    const float2* coord_f32;    // [HWp] (row = p / W as f32 true division, col = p % W): the reference's coordinates (f32 path)
+    float sig1_sq, sig2_sq;     // sigma^2 as f32 (f32 path: w = exp(-d2 / sigma^2), reference predict.py:173)
     const bf16_t* coord_tab;    // [HWp/32][2][32][8]    reference-side spatial channels
     const bf16_t* lab_hi;       // [cap][HWp/32][2][64][8] labels in MFMA A-operand order (hi part)
     const bf16_t* lab_lo;       // same, low part (probability mode) or nullptr

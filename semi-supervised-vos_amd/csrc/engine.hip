@@ -16,6 +16,7 @@
 #include "aux_kernels.h"
 #include "common.h"
 #include "prop_bf16.h"
+#include "prop_f32.h"
 #include "pointwise.h"
 #include "encoder_ops.h"
 
@@ -24,7 +25,8 @@ using namespace vosprop;
 namespace {
 
 struct Ring {
-    bf16_t* feat = nullptr;    // [cap][HWp][kC]
+    bf16_t* feat = nullptr;    // [cap][HWp][kC]          (VOSPROP_PREC_BF16)
+    float* featf = nullptr;    // [cap][HWp][kC] f32      (VOSPROP_PREC_F32: the features are never rounded)
     bf16_t* lab_hi = nullptr;  // [cap][tiles][2][64][8]
     bf16_t* lab_lo = nullptr;
     uint8_t* cls = nullptr;    // [cap][HWp]
@@ -63,6 +65,7 @@ struct vosprop_ctx {
     Ring ring;            // video state
     Ring scratch;         // stateless vosprop_predict
     bf16_t* coord_tab = nullptr;
+    float2* coord_f32 = nullptr;   // [HWp] the reference's f32 pixel coordinates (f32 path)
     float* part = nullptr;
     size_t part_bytes = 0;
     float* pred_buf = nullptr;     // (kMaxClasses, HW) f32
@@ -109,14 +112,18 @@ int fail(vosprop_ctx* ctx, int code, const std::string& msg) {
     } while (0)
 
 int ring_alloc(vosprop_ctx* ctx, Ring& r, int cap) {
-    const size_t feat_b = (size_t)cap * ctx->HWp * kC * sizeof(bf16_t);
+    const bool f32 = ctx->cfg.precision == VOSPROP_PREC_F32;
+    const size_t feat_b = (size_t)cap * ctx->HWp * kC * (f32 ? sizeof(float) : sizeof(bf16_t));
     const size_t lab_b = (size_t)cap * ctx->tiles * 2 * 64 * 8 * sizeof(bf16_t);
     const size_t cls_b = (size_t)cap * ctx->HWp;
-    HIP_TRY(ctx, hipMalloc((void**)&r.feat, feat_b));
+    void* fp = nullptr;
+    HIP_TRY(ctx, hipMalloc(&fp, feat_b));
+    if (f32) r.featf = (float*)fp;
+    else r.feat = (bf16_t*)fp;
     HIP_TRY(ctx, hipMalloc((void**)&r.lab_hi, lab_b));
     HIP_TRY(ctx, hipMalloc((void**)&r.lab_lo, lab_b));
     HIP_TRY(ctx, hipMalloc((void**)&r.cls, cls_b));
-    HIP_TRY(ctx, hipMemset(r.feat, 0, feat_b));
+    HIP_TRY(ctx, hipMemset(fp, 0, feat_b));
     HIP_TRY(ctx, hipMemset(r.lab_hi, 0, lab_b));
     HIP_TRY(ctx, hipMemset(r.lab_lo, 0, lab_b));
     HIP_TRY(ctx, hipMemset(r.cls, 0, cls_b));
@@ -126,6 +133,7 @@ int ring_alloc(vosprop_ctx* ctx, Ring& r, int cap) {
 
 void ring_free(Ring& r) {
     if (r.feat) (void)hipFree(r.feat);
+    if (r.featf) (void)hipFree(r.featf);
     if (r.lab_hi) (void)hipFree(r.lab_hi);
     if (r.lab_lo) (void)hipFree(r.lab_lo);
     if (r.cls) (void)hipFree(r.cls);
@@ -151,6 +159,17 @@ int build_coord_table(vosprop_ctx* ctx) {
     }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->coord_tab, tab.size() * 2));
     HIP_TRY(ctx, hipMemcpy(ctx->coord_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    return VOSPROP_OK;
+}
+
+// The reference's own coordinates (src/model/predict.py:167-168): row = index.div(float(W)) - a TRUE division of the flat index,
+// in f32 - and col = index % W, for the f32 path, which evaluates the prior from them op for op.  Host f32 arithmetic is IEEE.
+int build_coord_f32(vosprop_ctx* ctx) {
+    const int W = ctx->cfg.feat_w;
+    std::vector<float2> tab((size_t)ctx->HWp, make_float2(0.f, 0.f));
+    for (int p = 0; p < ctx->HW; ++p) tab[(size_t)p] = make_float2((float)p / (float)W, (float)(p % W));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->coord_f32, tab.size() * sizeof(float2)));
+    HIP_TRY(ctx, hipMemcpy(ctx->coord_f32, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
     return VOSPROP_OK;
 }
 
@@ -278,34 +297,45 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
     return VOSPROP_OK;
 }
 
-template <typename T>
-void launch_push(const void* src, bf16_t* dst, int HW, hipStream_t s) {
-    hipLaunchKernelGGL(push_kernel<T>, dim3((HW + 63) / 64, kC / 64), dim3(256), 0, s, (const T*)src, dst, HW);
+template <typename T, typename Out>
+void launch_push(const void* src, Out* dst, int HW, hipStream_t s) {
+    hipLaunchKernelGGL((push_kernel<T, Out>), dim3((HW + 63) / 64, kC / 64), dim3(256), 0, s, (const T*)src, dst, HW);
 }
 
-int push_features(vosprop_ctx* ctx, const void* src, int dtype, bf16_t* dst, hipStream_t s) {
+template <typename Out>
+int push_features_to(vosprop_ctx* ctx, const void* src, int dtype, Out* dst, int same_dt, hipStream_t s) {
     if (dtype & VOSPROP_LAYOUT_HWC) {   // channels-last source: rows are in ring order already
         const int n8 = ctx->HW * kC / 8;
         const dim3 grid((n8 + 255) / 256), block(256);
-        switch (dtype & ~VOSPROP_LAYOUT_HWC) {
-            case VOSPROP_DT_BF16:
-                HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)ctx->HW * kC * sizeof(bf16_t), hipMemcpyDeviceToDevice, s));
-                return VOSPROP_OK;
-            case VOSPROP_DT_F32: hipLaunchKernelGGL(push_hwc_kernel<float>, grid, block, 0, s, (const float*)src, dst, n8); break;
-            case VOSPROP_DT_F16: hipLaunchKernelGGL(push_hwc_kernel<__half>, grid, block, 0, s, (const __half*)src, dst, n8); break;
+        const int dt = dtype & ~VOSPROP_LAYOUT_HWC;
+        if (dt == same_dt) {
+            HIP_TRY(ctx, hipMemcpyAsync(dst, src, (size_t)ctx->HW * kC * sizeof(Out), hipMemcpyDeviceToDevice, s));
+            return VOSPROP_OK;
+        }
+        switch (dt) {
+            case VOSPROP_DT_F32: hipLaunchKernelGGL((push_hwc_kernel<float, Out>), grid, block, 0, s, (const float*)src, dst, n8); break;
+            case VOSPROP_DT_F16: hipLaunchKernelGGL((push_hwc_kernel<__half, Out>), grid, block, 0, s, (const __half*)src, dst, n8); break;
+            case VOSPROP_DT_BF16: hipLaunchKernelGGL((push_hwc_kernel<bf16_t, Out>), grid, block, 0, s, (const bf16_t*)src, dst, n8); break;
             default: return fail(ctx, VOSPROP_E_INVALID, "unknown feature dtype");
         }
         HIP_TRY(ctx, hipGetLastError());
         return VOSPROP_OK;
     }
     switch (dtype) {
-        case VOSPROP_DT_F32: launch_push<float>(src, dst, ctx->HW, s); break;
-        case VOSPROP_DT_F16: launch_push<__half>(src, dst, ctx->HW, s); break;
-        case VOSPROP_DT_BF16: launch_push<bf16_t>(src, dst, ctx->HW, s); break;
+        case VOSPROP_DT_F32: launch_push<float, Out>(src, dst, ctx->HW, s); break;
+        case VOSPROP_DT_F16: launch_push<__half, Out>(src, dst, ctx->HW, s); break;
+        case VOSPROP_DT_BF16: launch_push<bf16_t, Out>(src, dst, ctx->HW, s); break;
         default: return fail(ctx, VOSPROP_E_INVALID, "unknown feature dtype");
     }
     HIP_TRY(ctx, hipGetLastError());
     return VOSPROP_OK;
+}
+
+// features of one frame -> slot `slot` of the ring (bf16, or f32 unrounded on the parity path)
+int push_features(vosprop_ctx* ctx, const void* src, int dtype, Ring& r, int slot, hipStream_t s) {
+    const size_t off = (size_t)slot * ctx->HWp * kC;
+    if (r.featf) return push_features_to<float>(ctx, src, dtype, r.featf + off, VOSPROP_DT_F32, s);
+    return push_features_to<bf16_t>(ctx, src, dtype, r.feat + off, VOSPROP_DT_BF16, s);
 }
 
 // e0 / e1 (optional): HIP events attached to the dispatch itself (hipExtLaunchKernelGGL) - they carry the kernel's own start and
@@ -315,6 +345,16 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream
     const dim3 grid(lp.grid), block(kWaves * 64);
     if (mode == 1) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 1>), grid, block, 0, s, a); return; }
     if (mode == 2) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 2>), grid, block, 0, s, a); return; }
+    if (a.feat_f32) {   // VOSPROP_PREC_F32: the parity kernel (prop_f32.h)
+        if (lp.prob) {
+            if (lp.lab_lo) hipLaunchKernelGGL((prop_f32_kernel<true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((prop_f32_kernel<true, false>), grid, block, 0, s, a);
+        } else {
+            if (lp.lab_lo) hipLaunchKernelGGL((prop_f32_kernel<false, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((prop_f32_kernel<false, false>), grid, block, 0, s, a);
+        }
+        return;
+    }
     if (lp.prob) {
         if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<true, true, 0>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((prop_bf16_kernel<true, false, 0>), grid, block, 0, s, a);
@@ -344,12 +384,17 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     if (n_ref < 1 || n_ref > kMaxRef) return fail(ctx, VOSPROP_E_INVALID, "n_ref out of range");
     if (d < 1 || d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "d > VOSPROP_MAX_CLASSES");
     if (!(temperature > 0.0f)) return fail(ctx, VOSPROP_E_UNSUPPORTED, "temperature must be > 0");
-    if (ctx->cfg.precision != VOSPROP_PREC_BF16) return fail(ctx, VOSPROP_E_UNSUPPORTED, "precision not built");
+    const bool f32 = ctx->cfg.precision == VOSPROP_PREC_F32;
+    if (f32 && topk != 0) return fail(ctx, VOSPROP_E_UNSUPPORTED, "top-k is built on the bf16 path only");
     if (topk != 0 && prob) return fail(ctx, VOSPROP_E_UNSUPPORTED, "top-k is built for label propagation only");
     LastProp lp;
     PropArgs& a = lp.args;
     memset(&a, 0, sizeof(a));
     a.feat_ring = ring.feat;
+    a.feat_f32 = ring.featf;
+    a.coord_f32 = ctx->coord_f32;
+    a.sig1_sq = (float)((double)sigma1 * (double)sigma1);
+    a.sig2_sq = (float)((double)sigma2 * (double)sigma2);
     a.coord_tab = ctx->coord_tab;
     a.lab_hi = ring.lab_hi;
     a.lab_lo = lab_lo ? ring.lab_lo : nullptr;
@@ -390,7 +435,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.tk_m = ctx->tk_m;
     a.tk_cnt = ctx->tk_cnt;
     a.tk_cand = ctx->tk_cand;
-    const bool timed = ctx->timing && !topk && !prob && !lab_lo && ctx->tev_used + 2 <= 2 * 4096;
+    const bool timed = ctx->timing && !f32 && !topk && !prob && !lab_lo && ctx->tev_used + 2 <= 2 * 4096;
     if (timed) {
         while (ctx->tev.size() < ctx->tev_used + 2) {
             hipEvent_t e;
@@ -473,7 +518,7 @@ inline int nearest_src(int dst, int in_size, int out_size) {
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char* vosprop_version(void) { return "vosprop 0.1 (gfx950, bf16 MFMA)"; }
+const char* vosprop_version(void) { return "vosprop 0.2 (gfx950, bf16 MFMA + f32 MFMA parity path)"; }
 
 void vosprop_default_config(vosprop_config* cfg, int feat_h, int feat_w) {
     memset(cfg, 0, sizeof(*cfg));
@@ -568,11 +613,12 @@ int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, 
 
 /* test hook (GPU): every candidate algorithm the library returns for one pointwise-convolution problem, each timed and checked
  * against the f32 reference of csrc/pointwise.h on a zeroed and on a 0xFF-filled workspace.  rows: vosprop::PwCandidateReport
- * (index, workspace bytes, microseconds, worst err/tol clean, worst err/tol dirty, name[160]).  Returns the number of rows, or a
- * negative VOSPROP_E_* code.  Changes no plan. */
+ * (index, workspace bytes, microseconds, worst err/tol clean, worst err/tol dirty, repeats, repeats_bad, name[160]).  `repeats`
+ * further launches per candidate are each checked too (a racy algorithm fails only some); full != 0 checks EVERY output row
+ * instead of the 1 024 sampled ones.  Returns the number of rows, or a negative VOSPROP_E_* code.  Changes no plan. */
 int vosprop_debug_pointwise_candidates(const void* x, const void* weight, const void* bias, const void* residual, void* y,
                                        long long pixels, int cin, int cout, int relu, int dtype, void* stream, void* rows,
-                                       int cap_rows) {
+                                       int cap_rows, int repeats, int full) {
     hipDataType dt;
     switch (dtype) {
         case VOSPROP_DT_BF16: dt = HIP_R_16BF; break;
@@ -582,7 +628,7 @@ int vosprop_debug_pointwise_candidates(const void* x, const void* weight, const 
     }
     int n = 0;
     const int rc = pointwise_conv(x, weight, bias, residual, y, pixels, cin, cout, relu, dt, dtype, (hipStream_t)stream,
-                                  (PwCandidateReport*)rows, cap_rows, &n);
+                                  (PwCandidateReport*)rows, cap_rows, &n, repeats, full != 0);
     if (rc == 0) return n;
     return rc == 1 ? VOSPROP_E_INVALID : rc == 3 ? VOSPROP_E_UNSUPPORTED : VOSPROP_E_HIP;
 }
@@ -634,7 +680,8 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
         return VOSPROP_E_UNSUPPORTED;
     if (cfg->ref_num < 1 || cfg->ref_num > kMaxRef || cfg->frame_range < 0) return VOSPROP_E_INVALID;
     if (!(cfg->temperature > 0.0f) || !(cfg->sigma1 > 0.0f) || !(cfg->sigma2 > 0.0f)) return VOSPROP_E_INVALID;
-    if (cfg->precision != VOSPROP_PREC_BF16) return VOSPROP_E_UNSUPPORTED;
+    if (cfg->precision != VOSPROP_PREC_BF16 && cfg->precision != VOSPROP_PREC_F32) return VOSPROP_E_INVALID;
+    if (cfg->precision == VOSPROP_PREC_F32 && cfg->topk != 0) return VOSPROP_E_UNSUPPORTED;   // top-k: bf16 path only
     if (cfg->topk < 0 || cfg->topk > kTopkMax) return VOSPROP_E_UNSUPPORTED;
     if (cfg->topk != 0 && cfg->probability) return VOSPROP_E_UNSUPPORTED;
     int ndev = 0;
@@ -654,6 +701,7 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
     ctx->cfg.ring_capacity = cap;
     int rc = ring_alloc(ctx, ctx->ring, cap);
     if (!rc) rc = build_coord_table(ctx);
+    if (!rc) rc = build_coord_f32(ctx);
     if (!rc && hipMalloc((void**)&ctx->pred_buf, (size_t)kMaxClasses * ctx->HW * sizeof(float)) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipMalloc((void**)&ctx->up_tab, (size_t)(cfg->feat_h + cfg->feat_w + 2) * sizeof(int)) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipMalloc((void**)&ctx->cls_tmp, (size_t)ctx->HWp) != hipSuccess) rc = VOSPROP_E_HIP;
@@ -678,6 +726,7 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     ring_free(ctx->ring);
     ring_free(ctx->scratch);
     if (ctx->coord_tab) (void)hipFree(ctx->coord_tab);
+    if (ctx->coord_f32) (void)hipFree(ctx->coord_f32);
     if (ctx->up_tab) (void)hipFree(ctx->up_tab);
     if (ctx->part) (void)hipFree(ctx->part);
     for (Plan& p : ctx->plans) {
@@ -804,7 +853,7 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     const int f = ctx->frame_idx;
     const int slot = f % R.cap;
     const size_t lab_slot = (size_t)ctx->tiles * 2 * 64 * 8;
-    int rc = push_features(ctx, feat_dev, feat_dtype, R.feat + (size_t)slot * ctx->HWp * kC, s);
+    int rc = push_features(ctx, feat_dev, feat_dtype, R, slot, s);
     if (rc) return rc;
     if (f == 0) {   // reference inference_utils.py:33-48: frame 0 only seeds the history
         ctx->frame_idx = 1;
@@ -862,15 +911,14 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
     int slots[kMaxRef];
     for (int n = 0; n < n_ref; ++n) {
         slots[n] = n;
-        int rc = push_features(ctx, (const unsigned char*)ref_dev + (size_t)idx[n] * frame_elems * esz, feat_dtype,
-                               R.feat + (size_t)n * ctx->HWp * kC, s);
+        int rc = push_features(ctx, (const unsigned char*)ref_dev + (size_t)idx[n] * frame_elems * esz, feat_dtype, R, n, s);
         if (rc) return rc;
         // ref_label (d, T, HW): class stride T*HW floats, frame idx[n]
         rc = pack_labels_from_f32(ctx, ref_label_dev + (size_t)idx[n] * ctx->HW, (size_t)T * ctx->HW, d,
                                   R.lab_hi + n * lab_slot, R.lab_lo + n * lab_slot, R.cls + (size_t)n * ctx->HWp, s);
         if (rc) return rc;
     }
-    int rc = push_features(ctx, target_dev, feat_dtype, R.feat + (size_t)n_ref * ctx->HWp * kC, s);
+    int rc = push_features(ctx, target_dev, feat_dtype, R, n_ref, s);
     if (rc) return rc;
     return propagate(ctx, R, slots, n_ref, frame_idx, n_ref, d, probability != 0, true, sigma1, sigma2, temperature,
                      out_dev, ctx->cls_tmp, nullptr, nullptr, s);

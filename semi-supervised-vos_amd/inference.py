@@ -54,6 +54,9 @@ _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
 @click.option('--gpus', type=int, default=1, help='[engine] GPUs of this node to shard the videos over.')
 @click.option('--encoder-dtype', type=click.Choice(sorted(_DTYPES)), default='f16',
               help='[engine] encoder precision (default f16: the reference runs it under fp16 autocast on GPU).')
+@click.option('--propagation-precision', type=click.Choice(['bf16', 'f32']), default='bf16',
+              help='[engine] arithmetic of the propagation step: bf16 MFMA (fast path) or f32 MFMA with f32 features (the parity '
+                   'path: the reference\'s CPU arithmetic, ~1/16 of the matrix rate).')
 @click.option('--encoder-batch', type=int, default=32, help='[engine] frames per encoder call (look-ahead).')
 @click.option('--io-workers', type=int, default=None,
               help='[engine] JPEG decode processes (default: min(8, cores - 1); the reference uses 1).')
@@ -66,13 +69,15 @@ _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
 @click.option('--shard', type=(int, int), default=(0, 1), hidden=True, help='[engine] internal: rank, world')
 def inference_command(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                       inference_strategy, additional_model, additional_model_type, probability, scale, fusion, gpus,
-                      encoder_dtype, encoder_batch, io_workers, png_workers, miopen_find, encoder_graph, shard):
+                      encoder_dtype, propagation_precision, encoder_batch, io_workers, png_workers, miopen_find, encoder_graph,
+                      shard):
     if gpus > 1 and shard == (0, 1):
         return _launch_shards(gpus)
     inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_model, additional_model_type, probability, scale, fusion,
                            encoder_dtype=encoder_dtype, shard=shard, encoder_batch=encoder_batch, io_workers=io_workers,
-                           png_workers=png_workers, encoder_graph=encoder_graph, miopen_find=miopen_find)
+                           png_workers=png_workers, encoder_graph=encoder_graph, miopen_find=miopen_find,
+                           propagation_precision=propagation_precision)
 
 
 def visible_devices(n):
@@ -115,7 +120,7 @@ def _launch_shards(gpus):
 def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
                            reduction, disable=False, encoder_dtype='f16', shard=(0, 1), encoder_batch=32, io_workers=None,
-                           png_workers=2, encoder_graph=True, miopen_find=False):
+                           png_workers=2, encoder_graph=True, miopen_find=False, propagation_precision='bf16'):
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)
     if Config.DEVICE.type == 'cuda':
@@ -160,7 +165,8 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
     with torch.no_grad():
         head = (loader, len(dataset), annotation_dir, last_video, save, sigma_1, sigma_2, frame_range, ref_num,
                 temperature, probability_propagation)
-        opts = dict(encoder_dtype=dtype, stats=stats, encoder_batch=encoder_batch, png_workers=png_workers)
+        opts = dict(encoder_dtype=dtype, stats=stats, encoder_batch=encoder_batch, png_workers=png_workers,
+                    precision={'bf16': 0, 'f32': 1}[propagation_precision])
         if inference_strategy == 'single':
             inference_single(net, *head, disable, **opts)
         elif inference_strategy == 'hor-flip':

@@ -98,8 +98,9 @@ def encoded_frames(model, loader, device, encoder_dtype, batch):
 
 def inference_single(model, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                      frame_range, ref_num, temperature, probability_propagation, disable, encoder_dtype=None,
-                     stats=None, encoder_batch=32, png_workers=2):
-    """stats (optional dict) receives {'frames', 'videos', 'seconds'} for the fps report."""
+                     stats=None, encoder_batch=32, png_workers=2, precision=0):
+    """precision: VOSPROP_PREC_* of the propagation (0 = bf16 MFMA, 1 = the f32 parity path).
+    stats (optional dict) receives {'frames', 'videos', 'seconds'} for the fps report."""
     import time
     from tqdm import tqdm
     device = Config.DEVICE
@@ -133,7 +134,8 @@ def inference_single(model, inference_loader, total_len, annotation_dir, last_vi
                     eng.close()
                 eng = _engine.PropagationEngine(H_d, W_d, device=device.index or 0, ref_num=ref_num,
                                                 frame_range=frame_range, sigma1=sigma_1, sigma2=sigma_2,
-                                                temperature=temperature, probability=probability_propagation)
+                                                temperature=temperature, probability=probability_propagation,
+                                                precision=precision)
             eng.begin_video(label)
             if save is not None:   # reference predict.py:120-126: the annotation becomes 00000.png of the output
                 out_dir = Path(save) / current_video
@@ -243,7 +245,7 @@ def fuse_two(a, b, probability, reduction_str, unflip):
 
 def _inference_two_branch(strategy, models, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                           frame_range, ref_num, temperature, probability_propagation, scale, reduction_str, disable,
-                          encoder_dtype=None, stats=None, encoder_batch=32, png_workers=2):
+                          encoder_dtype=None, stats=None, encoder_batch=32, png_workers=2, precision=0):
     import time
     from tqdm import tqdm
     spec = _TWO_BRANCH[strategy]
@@ -253,7 +255,7 @@ def _inference_two_branch(strategy, models, inference_loader, total_len, annotat
     if probability_propagation and reduction_str not in REDUCTIONS:
         raise ValueError(f'unknown fusion {reduction_str!r}')
     kw = dict(ref_num=ref_num, frame_range=frame_range, sigma1=sigma_1, sigma2=sigma_2, temperature=temperature,
-              probability=probability_propagation)
+              probability=probability_propagation, precision=precision)
     chains = [_Chain(device, **kw), _Chain(device, **kw)]
     masks, palette, frame_idx, n_frames, videos = [], None, 0, 0, 0
     t0 = time.perf_counter()
@@ -334,7 +336,7 @@ def inference_multimodel(model, additional_model, inference_loader, total_len, a
 
 def inference_3_scale(model, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                       frame_range, ref_num, temperature, probability_propagation, scale, disable, encoder_dtype=None,
-                      stats=None, encoder_batch=32, output_size=THREE_SCALE_OUTPUT, png_workers=2):
+                      stats=None, encoder_batch=32, output_size=THREE_SCALE_OUTPUT, png_workers=2, precision=0):
     """reference inference_utils.py:514-595: three full passes over the loader at input scales [0.9, 1.0, scale] (nearest
     pre-scaling of the normalised image), each a single chain whose class maps are produced at `output_size` (the
     reference hard-codes 480x910 whatever the video size); the saved mask is the element-wise maximum of the three class
@@ -345,7 +347,7 @@ def inference_3_scale(model, inference_loader, total_len, annotation_dir, last_v
     if device.type != 'cuda':
         raise _engine.VospropError("--device cpu: the propagation engine is HIP-only (no CPU fallback)")
     chain = _Chain(device, ref_num=ref_num, frame_range=frame_range, sigma1=sigma_1, sigma2=sigma_2,
-                   temperature=temperature, probability=probability_propagation)
+                   temperature=temperature, probability=probability_propagation, precision=precision)
     per_video, palettes, order = {}, {}, []
     n_frames, videos = 0, 0
     t0 = time.perf_counter()

@@ -267,7 +267,8 @@ def test_every_library_candidate_against_the_f32_gate():
 
     class Row(ctypes.Structure):
         _fields_ = [('index', ctypes.c_int), ('workspace', ctypes.c_int), ('us', ctypes.c_float), ('worst_clean', ctypes.c_float),
-                    ('worst_dirty', ctypes.c_float), ('name', ctypes.c_char * 160)]
+                    ('worst_dirty', ctypes.c_float), ('repeats', ctypes.c_int), ('repeats_bad', ctypes.c_int),
+                    ('name', ctypes.c_char * 160)]
     torch.manual_seed(5)
     dev = torch.device('cuda', 0)
     dt = torch.bfloat16
@@ -280,19 +281,20 @@ def test_every_library_candidate_against_the_f32_gate():
     fn = native.lib().vosprop_debug_pointwise_candidates
     fn.restype = ctypes.c_int
     vp = ctypes.c_void_p
-    fn.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int]
+    fn.argtypes = [vp, vp, vp, vp, vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int,
+                   ctypes.c_int, ctypes.c_int]
     bias = conv.bias.detach()
     got = fn(x.data_ptr(), conv.weight.data_ptr(), bias.data_ptr(), r.data_ptr(), y.data_ptr(), n * h * w, 256, 1024, 1, 2,
-             torch.cuda.current_stream(dev).cuda_stream, ctypes.addressof(rows), 256)
+             torch.cuda.current_stream(dev).cuda_stream, ctypes.addressof(rows), 256, 20, 1)     # 20 more launches each, every row
     assert got > 0, got
-    lines = ['rank   algo workspace       us  worst err/tol: zeroed ws      0xFF ws       kernel']
+    lines = ['rank   algo workspace       us  worst err/tol: zeroed ws (1 + 20 launches, all rows)   bad launches      0xFF ws       kernel']
     n_ok = 0
     for i in range(got):
         R = rows[i]
         ok = 0.0 <= R.worst_clean <= 1.0
         n_ok += ok
         lines.append(f'{i:4d} {R.index:6d} {R.workspace:9d} {R.us:8.1f} {R.worst_clean:18.4g} {"ok " if ok else "BAD"} '
-                     f'{R.worst_dirty:12.4g} {"ok " if 0.0 <= R.worst_dirty <= 1.0 else "BAD"}  {R.name.decode(errors="replace")}')
+                     f'{R.repeats_bad:3d}/{R.repeats:<3d} {R.worst_dirty:12.4g} {"ok " if 0.0 <= R.worst_dirty <= 1.0 else "BAD"}  {R.name.decode(errors="replace")}')
     report = '\n'.join(lines)
     print(report)
     out = Path(__file__).resolve().parent.parent / 'gpurun_out'

@@ -126,3 +126,26 @@ def test_three_scale_strategy(goldens, prob):
     g = goldens[f"g7_3-scale_{'prob' if prob else 'label'}_masks"]
     assert masks.shape == g.shape == (case['T'] - 1,) + tuple(case['out3'])
     assert np.mean(masks == g) > 0.9995
+
+
+@pytest.mark.parametrize('prob', [False, True])
+@pytest.mark.parametrize('fi,topk', [(5, 0), (20, 0), (20, 7)])
+def test_predict_columns_is_a_slice_of_predict(prob, fi, topk):
+    """The column-subset form the full-size GPU tests use (tests/test_gpu_configs.py) equals the pinned oracle on those columns -
+    same ops, same order, so bit for bit up to the mm kernel's blocking (<= 1e-6 relative)."""
+    if prob and topk:
+        pytest.skip('top-k is label-propagation only')
+    rs = np.random.RandomState(fi * 31 + topk)
+    Hd, Wd, T, d = 9, 13, fi + 1, 4
+    feats = (rs.standard_normal((T, 64, Hd, Wd)) * 0.4).astype(np.float32)
+    lab = rs.randint(0, d, size=(T, Hd * Wd))
+    oh = np.zeros((d, T, Hd * Wd), np.float32)
+    tt, pp = np.meshgrid(np.arange(T), np.arange(Hd * Wd), indexing='ij')
+    oh[lab, tt, pp] = 1.0
+    wd, ws = vo.get_spatial_weight((Hd, Wd), 8.0), vo.get_spatial_weight((Hd, Wd), 21.0)
+    cols = np.array([0, 1, 12, 13, 57, 58, 103, Hd * Wd - 1])
+    assert torch.equal(vo.spatial_weight_columns((Hd, Wd), 8.0, cols), wd[:, cols])
+    full = vo.predict(feats[:fi], feats[fi], oh[:, :fi], None if prob else wd, None if prob else ws, fi, 40, 9, 1.0, prob,
+                      topk=topk).numpy()
+    part = vo.predict_columns(feats[:fi], feats[fi], oh[:, :fi], 8.0, 21.0, fi, 40, 9, 1.0, prob, cols, topk=topk).numpy()
+    assert np.allclose(part, full[:, cols], rtol=1e-6, atol=1e-12)
