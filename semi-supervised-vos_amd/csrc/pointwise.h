@@ -186,7 +186,6 @@ inline int pw_candidates() {      // VOSPROP_PW_CANDIDATES: how many of the libr
     }();
     return n;
 }
-inline bool pw_allow_streamk() { static const bool v = [] { const char* e = getenv("VOSPROP_PW_STREAMK"); return e && e[0] == '1'; }(); return v; }
 inline bool pw_verbose() { static const bool v = getenv("VOSPROP_PW_VERBOSE") != nullptr; return v; }
 
 inline float pw_eps_out(int dtype_key) {   // two roundings of the output type (VOSPROP_DT_*: 0 f32, 1 f16, 2 bf16)
@@ -427,7 +426,7 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
             if (hs != HIPBLAS_STATUS_SUCCESS || got <= 0) { P.dead = true; return 3; }
             // the library's ranking is a model (the winners measured on MI355X sit at ranks 2-43): time its candidates once on the
             // real operands - and let only those whose output passes the gate compete
-            int n_rejected = 0, n_streamk = 0;
+            int n_rejected = 0;
             if (report_n) *report_n = 0;
             for (int i = 0; i < got; ++i) {
                 if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > D.ws_bytes) continue;
@@ -454,15 +453,6 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
                     snprintf(R.name, sizeof(R.name), "%s", nm.c_str());
                 }
                 if (!ran) continue;
-                if (!pw_allow_streamk() && !report) {
-                    // stream-K kernels hand partial tiles from workgroup to workgroup inside one launch (flag + data through
-                    // L2s that are not coherent across XCDs).  Every one of them passed the gate on every box it was tried on,
-                    // but the round-1 driver run saw 6-half-ulp errors in a few elements that no deterministic candidate can
-                    // produce and that a one-shot check cannot exclude - the signature of such a hand-off read too early.
-                    // Not worth the 3-9 % they win on a layer: VOSPROP_PW_STREAMK=1 lets them compete again.
-                    const std::string nm = hipblaslt_ext::getSolutionNameFromAlgo(D.handle, res[i].algo);
-                    if (nm.find("_SK") != std::string::npos) { ++n_streamk; continue; }
-                }
                 if (!(worst <= 1.0f)) {
                     ++n_rejected;
                     if (pw_verbose())
@@ -479,8 +469,8 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
                 }
             }
             if (pw_verbose())
-                fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d (bias %d relu %d residual %d): %d candidates, %d rejected by the gate, %d stream-K set aside, algo %d wins, %.1f us\n",
-                        pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, n_rejected, n_streamk, best_index, best_ms * 1e3f);
+                fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d (bias %d relu %d residual %d): %d candidates, %d rejected by the gate, algo %d wins, %.1f us\n",
+                        pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, n_rejected, best_index, best_ms * 1e3f);
             if (report) return 0;
             if (!have) { P.dead = true; return 3; }
             pw_algo_cache_store(AC, ckey, best_index);

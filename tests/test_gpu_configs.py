@@ -197,7 +197,7 @@ def test_config4_thirty_videos_over_eight_shards(tmp_path):
     torch.manual_seed(0)
     torch.save({'state_dict': vn.VOSNet('resnet18').state_dict()}, tmp_path / 'ckpt.pth.tar')
     base = [sys.executable, 'main.py', 'inference', '-d', str(tmp_path / 'data'), '-r', str(tmp_path / 'ckpt.pth.tar'), '-m', 'resnet18',
-            '--ref_num', '5', '--frame_range', '6', '--io-workers', '1']
+            '--ref_num', '5', '--frame_range', '6', '--io-workers', '1', '--encoder-dtype', 'f32']
     one = subprocess.run(base + ['-s', str(tmp_path / 'one')], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     stats = []
@@ -212,8 +212,13 @@ def test_config4_thirty_videos_over_eight_shards(tmp_path):
             stats.append(st)
     assert sum(st['frames'] for st in stats) == sum(lengths) and sum(st['videos'] for st in stats) == 30
     assert [st['frames'] for st in stats] == load
+    # not bit-equal by construction: MIOpen's split-K convolutions accumulate with atomics, so encoder outputs - and on this
+    # random-init / noise dataset a near-tied pixel of the 8x12 map (1 % of a frame each) - can differ from process to process
+    diffs = []
     for vid, n in names.items():
         a = np.stack([np.asarray(Image.open(tmp_path / 'one' / vid / f'{i:05d}.png')) for i in range(n)])
         b = np.stack([np.asarray(Image.open(tmp_path / 'eight' / vid / f'{i:05d}.png')) for i in range(n)])
-        assert np.array_equal(a[0], b[0])
-        assert float(np.mean(a != b)) <= 0.01, vid
+        assert a.shape == b.shape and np.array_equal(a[0], b[0])
+        diffs.append(float(np.mean(a != b)))
+        assert diffs[-1] <= 0.03, vid
+    assert float(np.mean(diffs)) <= 0.005, diffs
