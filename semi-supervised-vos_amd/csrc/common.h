@@ -56,7 +56,8 @@ __host__ __device__ inline void split3(float x, float& h, float& m, float& l) {
 // and "extra" ones (the tail of the part, a sub-megabyte region that stays in L2 as well).
 struct Segment {
     int tt;        // target tile (kBT pixels)
-    int r_lo;      // first reference tile (index into the sampled stream: frame n = r / tiles_per_frame)
+    int r_lo;      // first reference tile; the stream is walked pixel tile by pixel tile with the N sampled frames inner:
+                   // r = pixel_tile * N + frame  (so a wave reuses its spatial-prior tile across the frames of a pixel tile)
     int n_steps;   // reference tiles in the run
     int slot;      // partial slot written by this segment: part[slot][part_rows][kBT]
 };

@@ -16,6 +16,7 @@
 #include "aux_kernels.h"
 #include "common.h"
 #include "prop_bf16.h"
+#include "prop_dense.h"
 #include "prop_f32.h"
 #include "pointwise.h"
 #include "encoder_ops.h"
@@ -352,6 +353,20 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream
         } else {
             if (lp.lab_lo) hipLaunchKernelGGL((prop_f32_kernel<false, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((prop_f32_kernel<false, false>), grid, block, 0, s, a);
+        }
+        return;
+    }
+    // dense path: the in-wave pipelined kernel (prop_dense.h).  VOSPROP_DENSE_TWO_BURST=1 selects the round-1 two-burst schedule of
+    // prop_bf16.h (same results; A/B timing only)
+    static const bool two_burst = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
+    if (!two_burst) {
+        if (lp.prob) {
+            if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<true, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((prop_dense_kernel<true, false>), grid, block, 0, s, a);
+        } else {
+            if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<false, true>), grid, block, 0, s, a);
+            else if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, e0, e1, 0, a);
+            else hipLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, a);
         }
         return;
     }

@@ -7,10 +7,13 @@
 //   * S^T tile = mfma(A = 32 reference pixels x K, B = K x 32 target pixels): every lane owns ONE target
 //     pixel (column) and 16 reference pixels (rows) of the 32x32 tile, so the column softmax statistics are
 //     in-register; the two half-waves share a column and exchange one value per tile (v_permlane32_swap).
-//   * K = 256 feature channels (16 x v_mfma_f32_32x32x16_bf16) + ONE extra 16-deep MFMA whose channels carry
-//     the Gaussian spatial prior:  -dist^2/(sigma^2 tau)  is bilinear in (reference coords, target coords)
-//     [dist^2 = Qp + Qt - a_p(2a_t + 2b_t/W) - b_p(2 gamma b_t + 2a_t/W)], so S_w = S + X comes out of the
-//     matrix core; 3-way bf16 splits of the real-valued factors keep ~24 significant bits.
+//   * K = 256 feature channels = 16 x v_mfma_f32_32x32x16_bf16 per tile.  The Gaussian spatial prior w[r,t] depends on the PIXEL
+//     positions only, not on the frame: the reference stream is walked pixel tile by pixel tile with the N sampled frames INNER, so
+//     a wave computes its 32x32 tile of w once per (pixel tile, sigma) - ONE extra 16-deep MFMA whose channels carry the prior
+//     [-dist^2/(sigma^2 tau) is bilinear in (reference coords, target coords): dist^2 = Qp + Qt - a_p(2a_t + 2b_t/W)
+//     - b_p(2 gamma b_t + 2a_t/W); 3-way bf16 splits of the real-valued factors keep ~24 significant bits] + 16 exponentials -
+//     keeps it in 16 registers, and every frame of that pixel tile then costs ONE exponential and one multiply per score
+//     (a = p w) instead of two exponentials: 1 + 2/N transcendentals per score instead of 2 (the kernel is VALU-issue bound).
 //   * numerators  out[k,t] = sum_r L[k,r] a[r,t]  are a second MFMA: the weighted probabilities a (already
 //     laid out rows-in-registers / column-on-lane) are packed to bf16 and used as the B operand against the
 //     label matrix stored in HBM in A-operand order.  Denominators stay f32 on the VALU.
@@ -67,6 +70,20 @@ constexpr float kRescaleThr = 8.0f;               // defer-max threshold in log2
 constexpr float kNegBig = -1.0e30f;
 constexpr float kSumThrV3 = 256.0f;              // 2^kRescaleThr, threshold on a tile's partial denominator
 
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at the wave-uniform byte address lds_dst.
+// Inline asm ON PURPOSE (cdna guide 5.7): hipcc counts a __builtin_amdgcn_global_load_lds in its s_waitcnt bookkeeping and, not
+// knowing which LDS bytes it writes, drains it - `s_waitcnt vmcnt(0)` before the next ds_read of the MFMA chain and before every
+// s_barrier - which exposes the L2 latency of a piece issued moments earlier inside the burst that was meant to hide it.  The asm
+// form is invisible to that pass: the kernel's own counted `s_waitcnt vmcnt(3)` at the end of a step (pieces issued one step
+// earlier) + the barrier that follows are what order the pieces before their readers.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
 __device__ __forceinline__ float half_max(float x) {   // max(x[lane], x[lane ^ 32]) in every lane
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -97,18 +114,15 @@ struct LabFrag {
     }
 };
 
-// A-operand fragments of a tile that are fetched ahead of its MFMA chain: channels 0..127 (8 x ds_read_b128)
-// and the 16 spatial channels.
+// A-operand fragments of a tile that are fetched ahead of its MFMA chain: channels 0..127 (8 x ds_read_b128).
 template <bool PROB>
 struct AFrag {
     bf16x8 a[8];
-    bf16x8 ax;
     // two halves so that the second one can be issued after the softmax has released its registers
     __device__ __forceinline__ void prefetch_lo(const unsigned char* lb, int j, int h) {
         const unsigned char* arow = lb + j * kRowB + h * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) a[ks] = *(const bf16x8*)(arow + ks * 32);
-        if (!PROB) ax = *(const bf16x8*)(lb + kOffCoord + h * 512 + j * 16);
     }
     __device__ __forceinline__ void prefetch_hi(const unsigned char* lb, int j, int h) {
         const unsigned char* arow = lb + j * kRowB + h * 16;
@@ -121,12 +135,12 @@ struct AFrag {
     }
 };
 
-// 16 + 1 MFMAs: S = R.T over the 256 channels, Sw = S + spatial term.  The first 8 fragments were prefetched during the
-// previous softmax burst; each MFMA is followed by the ds_read_b128 (immediate offset) that refills its slot with the
-// fragment 8 steps ahead, so the chain never waits on LDS.
+// 16 MFMAs: S = R.T over the 256 channels.  The first 8 fragments were prefetched during the previous softmax burst; each MFMA
+// is followed by the ds_read_b128 (immediate offset) that refills its slot with the fragment 8 steps ahead, so the chain never
+// waits on LDS.
 template <bool PROB, typename Hook>
-__device__ __forceinline__ void tile_scores(const unsigned char* lb, int j, int h, const bf16x8 (&Bt)[16],
-                                            const bf16x8& Bx, AFrag<PROB>& f, f32x16& S, f32x16& Sw, Hook&& hook) {
+__device__ __forceinline__ void tile_scores(const unsigned char* lb, int j, int h, const bf16x8 (&Bt)[16], AFrag<PROB>& f,
+                                            f32x16& S, Hook&& hook) {
     const unsigned char* arow = lb + j * kRowB + h * 16;
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[r] = 0.0f;
@@ -152,54 +166,73 @@ __device__ __forceinline__ void tile_scores(const unsigned char* lb, int j, int 
         hook(ks + 8);
     }
 #endif
-    if (!PROB) Sw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ax, Bx, S, 0, 0, 0);
 }
 
-// Online softmax update of one 32x32 score tile + label product.
-template <bool PROB, bool LAB_LO>
-__device__ __forceinline__ void tile_softmax(const LabFrag<LAB_LO>& lab, int h, f32x16& S, f32x16& Sw, ColState& st,
-                                             float c, float kq, bool tail, int rows_valid STAMP_ARGS) {
+// The prior tile of one (pixel tile, sigma): LW[r] = log2 w[r, t] = (-dist^2 g) c  [X from one 16-deep MFMA] - g Q_t c.
+// Dense mode keeps w = 2^LW (multiplied into the probabilities), the top-k passes keep LW (added to the exponent they rank by).
+template <bool KEEP_LOG>
+__device__ __forceinline__ void prior_tile(const unsigned char* lb, int j, int h, const bf16x8& Bx, float c, float kq, float (&Wt)[16]) {
+    const bf16x8 ax = *(const bf16x8*)(lb + kOffCoord + h * 512 + j * 16);
+    f32x16 X;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) X[r] = 0.0f;
+    X = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, Bx, X, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float lw = __builtin_fmaf(X[r], c, -kq);
+        Wt[r] = KEEP_LOG ? lw : __builtin_amdgcn_exp2f(lw);
+    }
+}
+
+// Online softmax update of one 32x32 score tile: p[r] = 2^((S[r] - m) c) against the running max, denominators updated.  The
+// label product of the tile (weights a = p w, bf16 packing, label MFMAs) is NOT done here: it is deferred to the wave's next
+// MFMA burst (label_product below), so this VALU-only burst - the longer of the two bursts of a step - gets shorter and the
+// deferred VALU work hides in the shadow of the score MFMAs of the same wave.
+template <bool PROB>
+__device__ __forceinline__ void tile_softmax(int h, f32x16& S, float (&p)[16], ColState& st, float c, bool tail,
+                                             int rows_valid STAMP_ARGS) {
     if (tail) {
         // padded reference rows of a frame's last tile must not enter the softmax (wave-uniform, rare)
         asm volatile("; tail tile" ::: "memory");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (acc_row(r, h) >= rows_valid) {
-                S[r] = kNegBig;
-                if (!PROB) Sw[r] = kNegBig;
-            }
-        }
+        for (int r = 0; r < 16; ++r)
+            if (acc_row(r, h) >= rows_valid) S[r] = kNegBig;
     }
     // Optimistic pass: exponentiate against the CURRENT running max; the running max is only raised (and this tile
     // redone) when some score exceeds it by more than kRescaleThr - rare after the first tiles.  The test is on the tile's
     // partial denominator (any term above 2^8, or an overflow, pushes the sum of 16 non-negative terms above 2^8; a false
     // alarm only costs a redo) - no per-tile max reduction at all.
     float mc = st.m * c;
-    float mq = mc + kq;
-    float e[16], p[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) e[r] = __builtin_fmaf(S[r], c, -mc);
     float l0 = 0.0f, l1 = 0.0f;   // two chains: halves the dependent-add latency
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
 #if VOSPROP_ABLATE & 1
-        const float pa = e[r], pb = e[r + 1];
-        p[r] = PROB ? pa : __builtin_fmaf(Sw[r], c, -mq);
-        p[r + 1] = PROB ? pb : __builtin_fmaf(Sw[r + 1], c, -mq);
+        const float pa = __builtin_fmaf(S[r], c, -mc), pb = __builtin_fmaf(S[r + 1], c, -mc);
 #else
-        const float pa = __builtin_amdgcn_exp2f(e[r]);
-        const float pb = __builtin_amdgcn_exp2f(e[r + 1]);
-        p[r] = PROB ? pa : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r], c, -mq));
-        p[r + 1] = PROB ? pb : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r + 1], c, -mq));
+        const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], c, -mc));
+        const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], c, -mc));
 #endif
-        l0 += pa;
-        l1 += pb;
+        if (PROB) {
+            // probability mode: the label product sees p rounded to bf16; the denominator must see THE SAME numbers, or the
+            // columns of the result sum to 1 +- 2^-9 instead of 1 (the reference's softmax columns sum to 1, and the class-axis
+            // fusion of its flip strategies breaks ties on exactly that).  Rounding here makes the bf16 conversion
+            // below exact.
+            p[r] = bf16_round(pa);
+            p[r + 1] = bf16_round(pb);
+            l0 += p[r];
+            l1 += p[r + 1];
+        } else {
+            p[r] = pa;
+            p[r + 1] = pb;
+            l0 += pa;
+            l1 += pb;
+        }
     }
     if (__any(l0 + l1 > kSumThrV3)) {
         // slow path: raise the running max (shared by the two half-waves of a column), rescale what was accumulated
         // against the old one exactly once, and redo this tile against the new one (cdna guide T13 hazard)
         asm volatile("; rescale" ::: "memory");
-        float u0, u1, u2, u3, u4, smax;   // max raw score of this column in this tile (from S itself: e loses it when
+        float u0, u1, u2, u3, u4, smax;   // max raw score of this column in this tile (from S itself: the exponent loses it when
                                           // the running max is still the -1e30 start value)
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u0) : "v"(S[0]), "v"(S[1]), "v"(S[2]));
         asm("v_max3_f32 %0, %1, %2, %3" : "=v"(u1) : "v"(S[3]), "v"(S[4]), "v"(S[5]));
@@ -217,34 +250,44 @@ __device__ __forceinline__ void tile_softmax(const LabFrag<LAB_LO>& lab, int h, 
         for (int r = 0; r < 16; ++r) st.Y[r] *= sc;
         st.m = mn;
         mc = mn * c;
-        mq = mc + kq;
         l0 = 0.0f;
         l1 = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             const float pa = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], c, -mc));
             const float pb = __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], c, -mc));
-            p[r] = PROB ? pa : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r], c, -mq));
-            p[r + 1] = PROB ? pb : __builtin_amdgcn_exp2f(__builtin_fmaf(Sw[r + 1], c, -mq));
-            l0 += pa;
-            l1 += pb;
+            if (PROB) {
+                p[r] = bf16_round(pa);
+                p[r + 1] = bf16_round(pb);
+                l0 += p[r];
+                l1 += p[r + 1];
+            } else {
+                p[r] = pa;
+                p[r + 1] = pb;
+                l0 += pa;
+                l1 += pb;
+            }
         }
     }
     st.l += l0 + l1;
-#ifdef VOSPROP_STAMP
-    STAMP_AT(6);
-#endif
-    bf16x8 pk0, pk1;
+}
+
+// The deferred label product of the PREVIOUS tile: Y[class, t] += L[class, rows] a[rows, t] with a = p w (label mode) packed to
+// bf16 - the rows-in-registers / column-on-lane layout of the accumulator IS the B-operand layout.  Two halves so that the
+// caller can spread the VALU part over the gaps of its score-MFMA chain.
+__device__ __forceinline__ bf16x8 pack_half(const float (&a)[16], int half) {
+    bf16x8 pk;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        pk0[e] = (bf16_t)p[e];
-        pk1[e] = (bf16_t)p[8 + e];
-    }
-    st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.h0, pk0, st.Y, 0, 0, 0);
-    st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.h1, pk1, st.Y, 0, 0, 0);
+    for (int e = 0; e < 8; ++e) pk[e] = (bf16_t)a[half * 8 + e];
+    return pk;
+}
+template <bool LAB_LO>
+__device__ __forceinline__ void label_mfmas(const LabFrag<LAB_LO>& lab, const bf16x8& pk0, const bf16x8& pk1, f32x16& Y) {
+    Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.h0, pk0, Y, 0, 0, 0);
+    Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.h1, pk1, Y, 0, 0, 0);
     if (LAB_LO) {
-        st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.l0, pk0, st.Y, 0, 0, 0);
-        st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.l1, pk1, st.Y, 0, 0, 0);
+        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.l0, pk0, Y, 0, 0, 0);
+        Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lab.l1, pk1, Y, 0, 0, 0);
     }
 }
 
@@ -285,26 +328,23 @@ __device__ __forceinline__ float max16v(const float (&v)[16]) {
     return r;
 }
 
-__device__ __forceinline__ void mask_tail_rows(f32x16& S, f32x16& Sw, int h, int rows_valid) {
+__device__ __forceinline__ void mask_tail_rows(f32x16& S, int h, int rows_valid) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if (acc_row(r, h) >= rows_valid) {
-            S[r] = kNegBig;
-            Sw[r] = kNegBig;
-        }
-    }
+    for (int r = 0; r < 16; ++r)
+        if (acc_row(r, h) >= rows_valid) S[r] = kNegBig;
 }
 
-__device__ __forceinline__ void tile_topk_pass1(f32x16& S, f32x16& Sw, float& colmax, TopkList& lst, int h, float c,
-                                                float kq, bool tail, int rows_valid) {
+// LW = log2 of the prior tile (prior_tile<true>): the weighted exponent the top-k ranks by is E = S c + LW.
+__device__ __forceinline__ void tile_topk_pass1(f32x16& S, const float (&LW)[16], float& colmax, TopkList& lst, int h, float c,
+                                                bool tail, int rows_valid) {
     if (tail) {
         asm volatile("; tail tile" ::: "memory");
-        mask_tail_rows(S, Sw, h, rows_valid);
+        mask_tail_rows(S, h, rows_valid);
     }
     float E[16], Sr[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        E[r] = __builtin_fmaf(Sw[r], c, -kq);
+        E[r] = __builtin_fmaf(S[r], c, LW[r]);
         Sr[r] = S[r];
     }
     colmax = vmaxf(colmax, max16v(Sr));
@@ -317,12 +357,12 @@ __device__ __forceinline__ void tile_topk_pass1(f32x16& S, f32x16& Sw, float& co
     }
 }
 
-__device__ __forceinline__ void tile_topk_pass2(f32x16& S, f32x16& Sw, float mc, float& lsum, int h, float c, float kq,
+__device__ __forceinline__ void tile_topk_pass2(f32x16& S, const float (&LW)[16], float mc, float& lsum, int h, float c,
                                                 float thr, bool tail, int rows_valid, unsigned row_base, int t,
                                                 const PropArgs& A) {
     if (tail) {
         asm volatile("; tail tile" ::: "memory");
-        mask_tail_rows(S, Sw, h, rows_valid);
+        mask_tail_rows(S, h, rows_valid);
     }
     float E[16];
     float l0 = 0.0f, l1 = 0.0f;
@@ -330,8 +370,8 @@ __device__ __forceinline__ void tile_topk_pass2(f32x16& S, f32x16& Sw, float mc,
     for (int r = 0; r < 16; r += 2) {
         l0 += __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], c, -mc));
         l1 += __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], c, -mc));
-        E[r] = __builtin_fmaf(Sw[r], c, -kq);
-        E[r + 1] = __builtin_fmaf(Sw[r + 1], c, -kq);
+        E[r] = __builtin_fmaf(S[r], c, LW[r]);
+        E[r + 1] = __builtin_fmaf(S[r + 1], c, LW[r + 1]);
     }
     lsum += l0 + l1;
     if (__any(max16v(E) >= thr)) {
@@ -350,6 +390,10 @@ __device__ __forceinline__ void tile_topk_pass2(f32x16& S, f32x16& Sw, float mc,
 template <bool PROB, bool LAB_LO, int MODE>
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArgs A) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kRing4 * kLdsBuf];
+    // per-lane constants of the prior (target-side MFMA fragment and g Q_t c for both sigmas): needed twice per 9 tiles, so they
+    // live in LDS (written and read by the same lane), not in 10 registers
+    __shared__ __attribute__((aligned(16))) bf16x8 s_bx[2][kWaves * 64];
+    __shared__ float s_kq[2][kWaves * 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -397,10 +441,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
         bf16x8 Bt[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) Bt[ks] = *(const bf16x8*)(trow + ks * 16);
+        // Consume the fragments HERE: hipcc otherwise sinks its counted waits for these 16 loads into the tile loop - a
+        // `s_waitcnt vmcnt(15) ... vmcnt(0)` ladder in front of the MFMAs of EVERY iteration - and the hardware counter those
+        // waits read also counts the LDS-DMA pieces in flight, so each score burst drained the pieces it had just issued.
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(Bt[ks]));
 
         // target-side spatial channels for both sigmas and the per-column constants g*Q_t*c
-        bf16x8 Bx1, Bx2;
-        float kq1 = 0.0f, kq2 = 0.0f;
         if (!PROB) {
             const int tq = t < A.HW ? t : A.HW - 1;
             const double at = (double)(tq / A.Wd), bt = (double)(tq % A.Wd);
@@ -424,12 +471,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
                 B[5] = (bf16_t)(h ? 0.0f : bl);
                 B[6] = (bf16_t)(h ? 0.0f : kh);
                 B[7] = (bf16_t)(h ? 0.0f : km);
-                if (sg) { Bx2 = B; kq2 = (float)(g * qt * (double)c); }
-                else { Bx1 = B; kq1 = (float)(g * qt * (double)c); }
+                s_bx[sg][tid] = B;
+                s_kq[sg][tid] = (float)(g * qt * (double)c);
             }
         }
-
-        asm volatile("" : "+v"(kq1), "+v"(kq2));   // keep the f64 derivation out of the tile loop
 
         TopkList lst;            // MODE 1 only
         float tk_thr = 3.0e38f;  // MODE 2 only
@@ -447,25 +492,20 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) st.Y[r] = 0.0f;
 
-        // Every thread runs the SAME stream, one step per reference tile p:
-        //     scores(p): fetch tile p+2 (HBM -> registers); label fragments of p; 17 MFMAs            | barrier
-        //     softmax(p): prefetch the first fragments of tile p+1; exp / sums / label MFMAs; stage p+2 | barrier
+        // Every thread runs the SAME stream, one step per reference tile:
+        //     scores(p): stage tile p+3 (LDS-DMA pieces from inside the MFMA burst); label fragments of p; 16 MFMAs        | barrier
+        //     softmax(p): prefetch the first fragments of tile p+1; (prior tile when the pixel tile or sigma changes;) exp / sums / label MFMAs | barrier
         // Group B runs one barrier late, so in every barrier interval one wave of a SIMD is in its MFMA burst and the
-        // other in its softmax burst.  Tile t sits in ring slot t % 3: written during step t-2, read during steps t-1
+        // other in its softmax burst.  Tile t sits in ring slot t & 3: written during step t-3, read during steps t-1
         // (prefetch) and t.
-        unsigned f_off = 0;          // byte offset of the staging cursor's tile inside its frame
-        int sn = 0, stile = 0;       // staging cursor (frame, tile-in-frame)
-        const unsigned char *f_base = nullptr, *lh_base = nullptr, *ll_base = nullptr;
-        auto stage_frame = [&]() {   // per-frame bases (wave-uniform; a scalar load per FRAME, not per tile)
-            const int slot = A.slot[sn];
-            f_base = (const unsigned char*)A.feat_ring + (size_t)slot * A.HWp * kC * 2;
-            lh_base = (const unsigned char*)A.lab_hi + (size_t)slot * TPF * kLdsLab;
-            if (LAB_LO) ll_base = (const unsigned char*)A.lab_lo + (size_t)slot * TPF * kLdsLab;
-        };
+        // The reference stream is walked PIXEL TILE BY PIXEL TILE WITH THE N FRAMES INNER: step index r = tile * N + frame.
+        const int N = A.n_ref;
+        const int slot_v = A.slot[lane];     // ring slot of sampled frame `lane` (kMaxRef = 64 = one per lane): per-tile frame
+                                             // switches read it with v_readlane, no memory access
+        int sn = 0, stile = 0;               // staging cursor (frame, pixel tile)
         auto stage_seek = [&](int step) {
-            sn = (r_lo + step) / TPF;
-            stile = (r_lo + step) - sn * TPF;
-            stage_frame();
+            stile = (r_lo + step) / N;
+            sn = (r_lo + step) - stile * N;
         };
         // Every wave issues exactly THREE pieces per tile (constant s_waitcnt count): two feature pieces and a third one by
         // role - wave 0 feature piece 16, wave 1 coordinates, waves 2-3 label hi, waves 4-5 label lo; waves without a third
@@ -474,41 +514,38 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
         // back they cost ~150 cycles of issue each (the vector-memory queue fills), spread out ~40.
         typedef __attribute__((address_space(3))) void* lds_ptr;
         typedef const __attribute__((address_space(1))) void* glb_ptr;
+        const unsigned smem_base = (unsigned)(size_t)(lds_ptr)smem;   // LDS byte address of the ring
         auto stage_piece = [&](int buf, int i) {   // i = 0, 1, 2
-            unsigned char* lds = smem + buf * kLdsBuf;
-            const unsigned char* f = f_base + (size_t)stile * kGlbFeat;
+            const unsigned lds = __builtin_amdgcn_readfirstlane(smem_base + (unsigned)(buf * kLdsBuf));
+            const int slot = __builtin_amdgcn_readlane(slot_v, sn);
+            const unsigned char* f = (const unsigned char*)A.feat_ring + ((size_t)slot * A.HWp + (size_t)stile * kTileR) * (kC * 2);
             if (i == 0) {
-                __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_a), (lds_ptr)(lds + wave * 1024), 16, 0, 0);
+                glds16(f + src_a, lds + wave * 1024);
             } else if (i == 1) {
-                __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_b), (lds_ptr)(lds + (wave + 8) * 1024), 16, 0, 0);
+                glds16(f + src_b, lds + (wave + 8) * 1024);
             } else if (wave == 0) {
-                __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_c), (lds_ptr)(lds + 16 * 1024), 16, 0, 0);
+                glds16(f + src_c, lds + 16 * 1024);
             } else if (wave == 1 && !PROB) {
-                __builtin_amdgcn_global_load_lds((glb_ptr)((const unsigned char*)A.coord_tab + (size_t)stile * kLdsCoord + lane * 16),
-                                                 (lds_ptr)(lds + kOffCoord), 16, 0, 0);
+                glds16((const unsigned char*)A.coord_tab + (size_t)stile * kLdsCoord + lane * 16, lds + kOffCoord);
             } else if (wave == 2 || wave == 3) {
-                __builtin_amdgcn_global_load_lds((glb_ptr)(lh_base + (size_t)stile * kLdsLab + (wave - 2) * 1024 + lane * 16),
-                                                 (lds_ptr)(lds + kOffLabHi + (wave - 2) * 1024), 16, 0, 0);
+                const unsigned char* lh = (const unsigned char*)A.lab_hi + ((size_t)slot * TPF + stile) * kLdsLab;
+                glds16(lh + (wave - 2) * 1024 + lane * 16, lds + kOffLabHi + (wave - 2) * 1024);
             } else if ((wave == 4 || wave == 5) && LAB_LO) {
-                __builtin_amdgcn_global_load_lds((glb_ptr)(ll_base + (size_t)stile * kLdsLab + (wave - 4) * 1024 + lane * 16),
-                                                 (lds_ptr)(lds + kOffLabLo + (wave - 4) * 1024), 16, 0, 0);
+                const unsigned char* ll = (const unsigned char*)A.lab_lo + ((size_t)slot * TPF + stile) * kLdsLab;
+                glds16(ll + (wave - 4) * 1024 + lane * 16, lds + kOffLabLo + (wave - 4) * 1024);
             } else {
-                __builtin_amdgcn_global_load_lds((glb_ptr)(f + src_a), (lds_ptr)(lds + wave * 1024), 16, 0, 0);
+                glds16(f + src_a, lds + wave * 1024);
             }
         };
         auto stage_advance = [&]() {   // next tile of the reference stream; stays on the last one at the end of the stream
-            int ns = stile + 1, nn = sn;
-            if (ns == TPF) {
-                ns = 0;
-                nn = sn + 1;
+            int nn = sn + 1, ns = stile;
+            if (nn == N) {
+                nn = 0;
+                ns = stile + 1;
             }
-            if (nn < A.n_ref) {
+            if (ns < TPF) {
+                sn = nn;
                 stile = ns;
-                if (nn != sn) {
-                    asm volatile("; next staged frame" ::: "memory");
-                    sn = nn;
-                    stage_frame();
-                }
             }
         };
         auto stage_issue = [&](int buf) {
@@ -517,7 +554,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             stage_piece(buf, 2);
             stage_advance();
         };
-        (void)f_off;
 
         // prologue: tiles 0, 1, 2 by everyone (past the end of a short segment: tiles nobody reads)
         stage_seek(0);
@@ -532,15 +568,31 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
 #ifdef VOSPROP_STAMP
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
-        // compute cursor + the per-frame operands of the tile being scored
-        int cn = r_lo / TPF, ctile = r_lo - cn * TPF;
+        // compute cursor (pixel tile, frame) and the prior tile of the wave's 32 x 32 (reference pixels, target pixels) block:
+        // w (dense mode) or log2 w (top-k passes) for the sigma of the frames being walked; recomputed when the pixel tile or the
+        // sigma class changes (N = 9, frame_idx > 15: twice per 9 tiles)
+        int ctile = r_lo / N, cn = r_lo - ctile * N;
         bool sparse = (A.sparse_mask >> cn) & 1ull;
-        float kq = sparse ? kq2 : kq1;
+        bool need_w = !PROB;
+        float Wt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Wt[r] = 0.0f;
+
+        // the deferred label product: probabilities and label fragments of the previous tile (zeros before the first one)
+        float pa[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pa[r] = 0.0f;
+        LabFrag<LAB_LO> lab_prev;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            lab_prev.h0[e] = (bf16_t)0.0f; lab_prev.h1[e] = (bf16_t)0.0f;
+            lab_prev.l0[e] = (bf16_t)0.0f; lab_prev.l1[e] = (bf16_t)0.0f;
+        }
 
         AFrag<PROB> fr;
         fr.prefetch(smem, j, h);
 #ifndef VOSPROP_PRIO_MODE
-#define VOSPROP_PRIO_MODE 2   // 2 = score (MFMA) burst at priority 1: -3.5 % measured; 1 = younger wave group at priority 1: null; 0 = off
+#define VOSPROP_PRIO_MODE 2   // 2 = score (MFMA) burst at priority 1: -3.5 % measured; 1 = younger wave group at priority 1: null; 3 = softmax burst at priority 1; 0 = off
 #endif
         if (VOSPROP_PRIO_MODE == 1 && grpB) __builtin_amdgcn_s_setprio(1);
         for (int p = 0; p < n_steps; ++p) {
@@ -555,11 +607,22 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             LabFrag<LAB_LO> lab;
             if (MODE == 0) lab.load(lb, lane);
             STAMP_AT(1);   // 1: label reads
-            f32x16 S, Sw;
+            f32x16 S;
+            bf16x8 pk0, pk1;
             if (VOSPROP_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(1);
-            tile_scores<PROB>(lb, j, h, Bt, sparse ? Bx2 : Bx1, fr, S, Sw, [&](int ks) {
+            tile_scores<PROB>(lb, j, h, Bt, fr, S, [&](int ks) {
                 if (!(VOSPROP_ABLATE & 4) && (ks == 2 || ks == 7 || ks == 12)) stage_piece(b_st, ks / 5);
+                if (MODE == 0) {
+                    // label product of tile p-1, VALU part, in the shadow of this tile's score MFMAs: a = p w, then bf16 packing
+                    if (!PROB && ks < 8) {
+                        pa[2 * ks] *= Wt[2 * ks];
+                        pa[2 * ks + 1] *= Wt[2 * ks + 1];
+                    }
+                    if (ks == 9) pk0 = pack_half(pa, 0);
+                    if (ks == 11) pk1 = pack_half(pa, 1);
+                }
             });
+            if (MODE == 0) label_mfmas<LAB_LO>(lab_prev, pk0, pk1, st.Y);
             if (!(VOSPROP_ABLATE & 4)) stage_advance();
             if (VOSPROP_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(0);
             STAMP_AT(2);   // 2: MFMA chain
@@ -568,27 +631,38 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             // ---- softmax(p) ----
             fr.prefetch_lo(lbn, j, h);   // first fragments of tile p+1 (harmless when p+1 == n_steps)
             STAMP_AT(4);   // 4: prefetch issue   (5: max + rescale decision, 6: exps + sums inside tile_softmax)
+            if (!PROB && need_w) {       // wave-uniform, 2 of 9 tiles at N = 9
+                asm volatile("; prior tile" ::: "memory");
+                prior_tile<MODE != 0>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c, s_kq[sparse ? 1 : 0][tid], Wt);
+                need_w = false;
+            }
             const bool tail = ragged && ctile == TPF - 1;
+            if (VOSPROP_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(1);
             if (MODE == 0) {
-                tile_softmax<PROB, LAB_LO>(lab, h, S, Sw, st, c, kq, tail, rows_last STAMP_PASS);
+                tile_softmax<PROB>(h, S, pa, st, c, tail, rows_last STAMP_PASS);
+                lab_prev = lab;
             } else if (MODE == 1) {
-                tile_topk_pass1(S, Sw, st.m, lst, h, c, kq, tail, rows_last);
+                tile_topk_pass1(S, Wt, st.m, lst, h, c, tail, rows_last);
             } else {
-                tile_topk_pass2(S, Sw, st.m * c, st.l, h, c, kq, tk_thr, tail, rows_last,
+                tile_topk_pass2(S, Wt, st.m * c, st.l, h, c, tk_thr, tail, rows_last,
                                 (unsigned)(cn * A.HWp + ctile * kTileR), t, A);
             }
+            if (VOSPROP_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(0);
             STAMP_AT(7);   // 7: pack + label MFMAs
             fr.prefetch_hi(lbn, j, h);
             // this wave's pieces of tile p+2 have landed; the 3 of tile p+3 may stay in flight (loads return in order).  Top-k
             // pass 2 also issues atomics and stores, which share the counter: it waits for everything
             if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            if (++ctile == TPF) {   // the next tile starts a new reference frame: its sigma may differ
-                asm volatile("; next scored frame" ::: "memory");
-                ctile = 0;
-                ++cn;
-                sparse = (A.sparse_mask >> cn) & 1ull;
-                kq = sparse ? kq2 : kq1;
+            if (++cn == N) {        // next pixel tile: a new prior tile
+                cn = 0;
+                ++ctile;
+                need_w = !PROB;
+            }
+            {
+                const bool sp = (A.sparse_mask >> cn) & 1ull;     // the next frame's sigma class (changes once per pixel tile)
+                if (sp != sparse) need_w = !PROB;
+                sparse = sp;
             }
             STAMP_AT(8);   // 8: DMA wait + frame bookkeeping
             // (barrier 2 was also tried BEFORE the tail - prefetch_hi, DMA wait, bookkeeping - to even out the two intervals of a
@@ -598,6 +672,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the look-ahead pieces before the ring is re-staged
         if (!grpB) __syncthreads();
+        if (MODE == 0) {   // the last tile's label product
+            if (!PROB) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pa[r] *= Wt[r];
+            }
+            label_mfmas<LAB_LO>(lab_prev, pack_half(pa, 0), pack_half(pa, 1), st.Y);
+        }
 #ifdef VOSPROP_STAMP
         if (A.dbg && lane == 0)
             for (int k = 0; k < VOSPROP_NSTAMP; ++k)

@@ -1,0 +1,397 @@
+// The dense propagation kernel, software-pipelined INSIDE the wave (the shipped hot kernel for topk == 0).
+//
+// Same arithmetic, LDS layout, work decomposition and partial format as prop_bf16.h (which keeps the two top-k passes), another
+// schedule.  What the round-2 stamps of the two-burst kernel showed (profiles/r02_*): with a wave in its MFMA burst and its SIMD
+// partner in its softmax burst, BOTH bursts take ~900 cycles - the sum of what they take alone (~600 + ~300): two waves of one SIMD
+// do not overlap matrix and vector work, while up to five single-issue VALU instructions DO hide in the 32-cycle shadow of an MFMA
+// of the SAME wave (tools/ubench_issue.hip; MI355X_MICROARCH "issue cost" rows).  So here every wave runs ONE continuous stream:
+//
+//     step p:   S(p)  = 16 score MFMAs of tile p, and in the gap after MFMA ks, row ks of the softmax of tile p-1:
+//                       e = S(p-1)[ks] c - m c ;  q = 2^e ;  l += q ;  a = q w[ks] ;  (odd ks) pack a pair to bf16
+//                       - 4.25 VALU instructions with ONE transcendental per gap (the prior tile w is per pixel tile, prop_bf16.h) -
+//                       plus the gap's LDS fragment read (tile p second half / tile p+1 first half) and, in three gaps, one LDS-DMA
+//                       piece of tile p+3;
+//               then the rare rescale check of tile p-1, its two label MFMAs, the prior tile if the pixel tile / sigma changed,
+//               `s_waitcnt vmcnt(3)` and ONE barrier.
+//
+// Tile t lives in LDS ring slot t % 5: written by DMA during step t-3, first fragments read during step t-1, the rest and the
+// coordinates during step t, the LABELS during step t+1 (when its label product runs - so they need no registers in between); the
+// slot is re-targeted by the DMA of step t+2, i.e. after the barrier that ends step t+1.  The loop is unrolled by two so that the
+// score accumulators of "this" and "the previous" tile swap roles without copies.
+#pragma once
+#include "common.h"
+#include "prop_bf16.h"
+
+#ifndef VOSPROP_DABLATE
+#define VOSPROP_DABLATE 0   // timing experiments only (tools/dense_ablate.sh; results are WRONG by construction): 1 = no softmax VALU in
+                            // the chain, 2 = no LDS fragment refills, 4 = no staging, 8 = no per-step barrier, 16 = no score MFMAs
+#endif
+
+namespace vosprop {
+
+constexpr int kRing5 = 5;   // LDS ring slots of the dense kernel (112 640 B + 20 KiB of per-lane constants <= 160 KiB)
+
+// rows 0..15 of one tile's softmax against the running max (mc = m c), sequential form (rescale path and the segment's last tile)
+template <bool PROB>
+__device__ __forceinline__ void softmax_rows(const f32x16& Sp, const float (&Wt)[16], float c, float mc, float& lt0, float& lt1,
+                                             bf16x8& pk0, bf16x8& pk1) {
+    lt0 = 0.0f;
+    lt1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float qa = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[r], c, -mc));
+        const float qb = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[r + 1], c, -mc));
+        bf16_t ha, hb;
+        if (PROB) {       // the denominator sees the numbers the label product sees (columns sum to 1, see prop_bf16.h)
+            ha = (bf16_t)qa;
+            hb = (bf16_t)qb;
+            lt0 += (float)ha;
+            lt1 += (float)hb;
+        } else {
+            lt0 += qa;
+            lt1 += qb;
+            ha = (bf16_t)(qa * Wt[r]);
+            hb = (bf16_t)(qb * Wt[r + 1]);
+        }
+        if (r < 8) { pk0[r] = ha; pk0[r + 1] = hb; }
+        else { pk1[r - 8] = ha; pk1[r - 7] = hb; }
+    }
+}
+
+template <bool PROB, bool LAB_LO>
+__global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropArgs A) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kRing5 * kLdsBuf];
+    __shared__ __attribute__((aligned(16))) bf16x8 s_bx[2][kWaves * 64];   // per-lane prior constants (see prop_bf16.h)
+    __shared__ float s_kq[2][kWaves * 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31;       // MFMA row (A operand) / column (B operand, C/D)
+    const int h = lane >> 5;       // k-half of the operand fragments / row-half of the accumulator
+    const int TPF = A.tiles_per_frame;
+    const int N = A.n_ref;
+    const float c = A.c;
+    const bool ragged = A.HW != A.HWp;
+    const int rows_last = A.HW - (TPF - 1) * kTileR;   // valid rows of a frame's last tile
+
+    // ---- staging roles: every wave issues exactly THREE LDS-DMA pieces per tile (prop_bf16.h: 17 feature pieces in the padded
+    // 528-B row image, 1 coordinate piece, 2 + 2 label pieces).  Pieces 1 and 2 are feature pieces w and w + 8; the third piece
+    // is chosen ONCE per wave as (base pointer, per-slot stride, per-tile stride, LDS offset) so that the tile loop has no role
+    // branches: wave 0 feature piece 16, wave 1 coordinates, waves 2-3 label hi, waves 4-5 label lo, the rest repeat piece 1.
+    auto feat_src_off = [&](int piece) -> unsigned {
+        int qq = 64 * piece + lane;
+        if (qq >= kTileR * 33) qq = 0;   // lanes past the image (piece 16, lanes 32-63): any valid source, lands in slack
+        int row = qq / 33, ch = qq - row * 33;
+        if (ch == 32) ch = 31;
+        return (unsigned)(row * 512 + ch * 16);
+    };
+    const unsigned src_a = feat_src_off(wave), src_b = feat_src_off(wave + 8);
+    const size_t feat_slot_stride = (size_t)A.HWp * (kC * 2);
+    const unsigned char* third_base = (const unsigned char*)A.feat_ring;
+    size_t third_slot_stride = feat_slot_stride;
+    unsigned third_tile_stride = kGlbFeat, third_lane = src_a, third_lds = (unsigned)wave * 1024;
+    if (wave == 0) {
+        third_lane = feat_src_off(16);
+        third_lds = 16 * 1024;
+    } else if (wave == 1 && !PROB) {
+        third_base = (const unsigned char*)A.coord_tab;
+        third_slot_stride = 0;
+        third_tile_stride = kLdsCoord;
+        third_lane = lane * 16;
+        third_lds = kOffCoord;
+    } else if (wave == 2 || wave == 3) {
+        third_base = (const unsigned char*)A.lab_hi + (wave - 2) * 1024;
+        third_slot_stride = (size_t)TPF * kLdsLab;
+        third_tile_stride = kLdsLab;
+        third_lane = lane * 16;
+        third_lds = kOffLabHi + (wave - 2) * 1024;
+    } else if ((wave == 4 || wave == 5) && LAB_LO) {
+        third_base = (const unsigned char*)A.lab_lo + (wave - 4) * 1024;
+        third_slot_stride = (size_t)TPF * kLdsLab;
+        third_tile_stride = kLdsLab;
+        third_lane = lane * 16;
+        third_lds = kOffLabLo + (wave - 4) * 1024;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned smem_base = (unsigned)(size_t)(lds_ptr)smem;   // LDS byte address of the ring
+    const int slot_v = A.slot[lane];     // ring slot of sampled frame `lane` (kMaxRef = 64 = one per lane), read with v_readlane
+
+    const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
+    for (int si = seg0; si < seg1; ++si) {
+        const Segment sg = A.segs[si];
+        const int tt = __builtin_amdgcn_readfirstlane(sg.tt);
+        const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);
+        const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
+        const int part_slot = __builtin_amdgcn_readfirstlane(sg.slot);
+
+        // target (B operand) fragments: 32 columns x 256 channels per wave, resident in registers
+        const int t = tt * kBT + wave * kColsPerWave + j;
+        const int t_ld = t < A.HWp ? t : A.HWp - 1;
+        const bf16_t* trow = A.feat_ring + ((size_t)A.target_slot * A.HWp + t_ld) * kC + h * 8;
+        bf16x8 Bt[16];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) Bt[ks] = *(const bf16x8*)(trow + ks * 16);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(Bt[ks]));   // hipcc's waits for these loads stay out of the tile loop
+
+        // target-side spatial channels for both sigmas and the per-column constants g Q_t c -> LDS (own lane writes, own lane reads)
+        if (!PROB) {
+            const int tq = t < A.HW ? t : A.HW - 1;
+            const double at = (double)(tq / A.Wd), bt = (double)(tq % A.Wd);
+            const double tw = A.two_over_w, gm = A.gamma;
+            const double qt = at * at + tw * at * bt + gm * bt * bt;
+#pragma unroll
+            for (int sgm = 0; sgm < 2; ++sgm) {
+                const double g = sgm ? A.g2 : A.g1;
+                float ah, am, al, bh, bm, bl, kh, km, kl;
+                split3((float)(g * (2.0 * at + tw * bt)), ah, am, al);
+                split3((float)(g * (2.0 * gm * bt + tw * at)), bh, bm, bl);
+                split3((float)(-g), kh, km, kl);
+                bf16x8 B;   // pairs with the reference-side table of engine.hip build_coord_table (prop_bf16.h has the derivation)
+                B[0] = (bf16_t)(h ? kl : ah);
+                B[1] = (bf16_t)(h ? kh : am);
+                B[2] = (bf16_t)(h ? km : al);
+                B[3] = (bf16_t)(h ? kh : bh);
+                B[4] = (bf16_t)(h ? 0.0f : bm);
+                B[5] = (bf16_t)(h ? 0.0f : bl);
+                B[6] = (bf16_t)(h ? 0.0f : kh);
+                B[7] = (bf16_t)(h ? 0.0f : km);
+                s_bx[sgm][tid] = B;
+                s_kq[sgm][tid] = (float)(g * qt * (double)c);
+            }
+        }
+
+        ColState st;
+        st.m = kNegBig;
+        st.l = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.Y[r] = 0.0f;
+        float Wt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Wt[r] = 0.0f;
+
+        // ---- staging cursor (frame inner) and the three pieces of a tile ----
+        int sn = 0, stile = 0;
+        auto stage_seek = [&](int step) {
+            stile = (r_lo + step) / N;
+            sn = (r_lo + step) - stile * N;
+        };
+        auto stage_piece = [&](int buf, int i) __attribute__((always_inline)) {
+            const unsigned lds = __builtin_amdgcn_readfirstlane(smem_base + (unsigned)(buf * kLdsBuf));
+            const int slot = __builtin_amdgcn_readlane(slot_v, sn);
+            if (i < 2) {
+                const unsigned char* f = (const unsigned char*)A.feat_ring + (size_t)slot * feat_slot_stride + (size_t)stile * kGlbFeat;
+                if (i == 0) glds16(f + src_a, lds + wave * 1024);
+                else glds16(f + src_b, lds + (wave + 8) * 1024);
+            } else {
+                glds16(third_base + (size_t)slot * third_slot_stride + (size_t)stile * third_tile_stride + third_lane, lds + third_lds);
+            }
+        };
+        auto stage_advance = [&]() __attribute__((always_inline)) {   // next tile of the stream; stays on the last one at its end
+            int nn = sn + 1, ns = stile;
+            if (nn == N) {
+                nn = 0;
+                ns = stile + 1;
+            }
+            if (ns < TPF) {
+                sn = nn;
+                stile = ns;
+            }
+        };
+        // "tile -1" (the first step's previous tile) has probabilities 0 and takes its labels from slot 4: zero them, or stale LDS
+        // bits that happen to spell a NaN would turn 0 x NaN into the accumulators
+        if (tid < 2 * kLdsLab / 16) *(f32x4*)(smem + 4 * kLdsBuf + kOffLabHi + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage_seek(0);
+        for (int q = 0; q < 3; ++q) {   // prologue: tiles 0, 1, 2
+            stage_piece(q, 0);
+            stage_piece(q, 1);
+            stage_piece(q, 2);
+            stage_advance();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        // compute cursor (pixel tile, frame) of the tile whose SCORES are being computed
+        int ctile = r_lo / N, cn = r_lo - ctile * N;
+        bool sparse = (A.sparse_mask >> cn) & 1ull;
+        bool need_w = !PROB;
+
+        AFrag<PROB> fr;
+        fr.prefetch(smem, j, h);
+
+        f32x16 S0, S1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S1[r] = -__builtin_inff();   // "tile -1": every probability 0 (whatever labels slot 4 holds)
+        // ring slots of tile p (cur), p+1 (nxt), p-1 (prv), p+3 (stg): counters modulo 5
+        int s_cur = 0, s_nxt = 1, s_prv = 4, s_stg = 3;
+        auto ring_advance = [&]() __attribute__((always_inline)) {
+            s_prv = s_cur;
+            s_cur = s_nxt;
+            s_nxt = s_nxt == 4 ? 0 : s_nxt + 1;
+            s_stg = s_stg == 4 ? 0 : s_stg + 1;
+        };
+
+        // finish tile p-1: rescale check (rare), denominators, label MFMAs
+        auto finish_prev = [&](const f32x16& Sp, const LabFrag<LAB_LO>& labp, float lt0, float lt1, bf16x8& pk0, bf16x8& pk1) __attribute__((always_inline)) {
+            if (__any(lt0 + lt1 > kSumThrV3)) {
+                // raise the running max (shared by the two half-waves of a column), rescale what was accumulated against the old
+                // one exactly once, redo this tile against the new one (cdna guide T13 hazard; Y does not hold this tile yet)
+                asm volatile("; rescale" ::: "memory");
+                float sv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] = Sp[r];
+                const float mn = fmaxf(st.m, half_max(max16v(sv)));
+                const float sc = __builtin_amdgcn_exp2f((st.m - mn) * c);
+                st.l *= sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st.Y[r] *= sc;
+                st.m = mn;
+                softmax_rows<PROB>(Sp, Wt, c, mn * c, lt0, lt1, pk0, pk1);
+            }
+            st.l += lt0 + lt1;
+            label_mfmas<LAB_LO>(labp, pk0, pk1, st.Y);
+        };
+
+        // one step: scores of tile p into S, softmax of tile p-1 (scores Sp, labels labp) in the gaps of the chain
+        auto step = [&](f32x16& S, const f32x16& Sp) __attribute__((always_inline)) {
+            const unsigned char* lb = smem + s_cur * kLdsBuf;
+            const unsigned char* lbn = smem + s_nxt * kLdsBuf;
+            const int b_st = s_stg;
+            LabFrag<LAB_LO> labp;
+            const float mc = st.m * c;
+            float lt0 = 0.0f, lt1 = 0.0f, qprev = 0.0f;
+            bf16x8 pk0, pk1;
+            const unsigned char* arow = lb + j * kRowB + h * 16;
+            const unsigned char* nrow = lbn + j * kRowB + h * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+#if VOSPROP_DABLATE & 16
+                asm volatile("" : "+v"(fr.a[ks & 7]));
+#else
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[ks & 7], Bt[ks], S, 0, 0, 0);
+#endif
+                // refill the fragment slot just consumed: second half of this tile, then the first half of the next one
+#if !(VOSPROP_DABLATE & 2)
+                if (ks < 8) fr.a[ks] = *(const bf16x8*)(arow + (ks + 8) * 32);
+                else fr.a[ks - 8] = *(const bf16x8*)(nrow + (ks - 8) * 32);
+#endif
+#if !(VOSPROP_DABLATE & 4)
+                if (ks == 2 || ks == 7 || ks == 12) stage_piece(b_st, ks / 5);
+#endif
+                if (ks == 10) labp.load(smem + s_prv * kLdsBuf, lane);   // labels of tile p-1, for the label MFMAs after the chain
+                // row ks of the previous tile
+#if VOSPROP_DABLATE & 1
+                const float q = Sp[ks];
+                if (ks == 15) { pk0 = Bt[0]; pk1 = Bt[1]; }
+                if (false)
+#else
+                const float q = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[ks], c, -mc));
+#endif
+                if (PROB) {
+                    if (ks & 1) {
+                        const bf16_t ha = (bf16_t)qprev, hb = (bf16_t)q;
+                        lt0 += (float)ha;
+                        lt1 += (float)hb;
+                        if (ks < 8) { pk0[ks - 1] = ha; pk0[ks] = hb; }
+                        else { pk1[ks - 9] = ha; pk1[ks - 8] = hb; }
+                    } else {
+                        qprev = q;
+                    }
+                } else {
+                    if (ks & 1) lt1 += q;
+                    else lt0 += q;
+                    const float aq = q * Wt[ks];
+                    if (ks & 1) {
+                        if (ks < 8) { pk0[ks - 1] = (bf16_t)qprev; pk0[ks] = (bf16_t)aq; }
+                        else { pk1[ks - 9] = (bf16_t)qprev; pk1[ks - 8] = (bf16_t)aq; }
+                    } else {
+                        qprev = aq;
+                    }
+                }
+#ifndef VOSPROP_DENSE_NO_SGB
+                // pin the interleave (cdna guide T19): after each score MFMA its fragment refill and the 4-5 VALU instructions
+                // of one softmax row, in the MFMA's shadow - hipcc otherwise sinks the multiplies and packings below the chain
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // <= 5 VALU (one of them the exponential)
+#endif
+            }
+            // the packed weights are "used" here, in the chain's basic block: hipcc otherwise sinks the multiplies and packings of the
+            // fast path below the rescale branch, out of the MFMA shadow
+            asm volatile("" : "+v"(pk0), "+v"(pk1));
+            stage_advance();
+            finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
+            // tile p: padded rows of a frame's last tile never enter the softmax (wave-uniform, rare)
+            if (ragged && ctile == TPF - 1) {
+                asm volatile("; tail tile" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (acc_row(r, h) >= rows_last) S[r] = kNegBig;
+            }
+            // the prior tile of tile p (used from the next step on; tile p-1 is finished)
+            if (!PROB && need_w) {
+                asm volatile("; prior tile" ::: "memory");
+                prior_tile<false>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c, s_kq[sparse ? 1 : 0][tid], Wt);
+                need_w = false;
+            }
+            if (++cn == N) {
+                cn = 0;
+                ++ctile;
+                need_w = !PROB;
+            }
+            {
+                const bool sp = (A.sparse_mask >> cn) & 1ull;
+                if (sp != sparse) need_w = !PROB;
+                sparse = sp;
+            }
+            // this wave's pieces of tile p+2 have landed (the 3 of tile p+3 may stay in flight); the barrier then makes every
+            // wave's pieces of p+2 visible and retires slot (p & 3) for the DMA of step p+1
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#if !(VOSPROP_DABLATE & 8)
+            __syncthreads();
+#endif
+            ring_advance();
+        };
+
+        int p = 0;
+        for (; p + 1 < n_steps; p += 2) {
+            step(S0, S1);
+            step(S1, S0);
+        }
+        // the segment's last tile has no chain to hide under (its labels sit in slot s_prv after the last ring_advance)
+        auto drain = [&](const f32x16& Sp) __attribute__((always_inline)) {
+            float lt0, lt1;
+            bf16x8 pk0, pk1;
+            LabFrag<LAB_LO> labp;
+            labp.load(smem + s_prv * kLdsBuf, lane);
+            softmax_rows<PROB>(Sp, Wt, c, st.m * c, lt0, lt1, pk0, pk1);
+            finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
+        };
+        if (p < n_steps) {
+            step(S0, S1);
+            drain(S0);
+        } else {
+            drain(S1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the look-ahead pieces before the ring is re-staged
+        __syncthreads();
+
+        // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
+        float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + j;
+        const float lsum = half_sum(st.l);
+        if (h == 0) {
+            part[0] = st.m;
+            part[kBT] = lsum;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cls = acc_row(r, h);
+            if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
+        }
+    }
+}
+
+}  // namespace vosprop

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_f32_kernel(const PropArgs
     const int j = lane & 31;       // MFMA row (A operand) / column (B operand, C/D)
     const int h = lane >> 5;       // k-half of the operands / row-half of the accumulator
     const int TPF = A.tiles_per_frame;
+    const int N = A.n_ref;
     const float c = A.c;
     const bool ragged = A.HW != A.HWp;
     const int rows_last = A.HW - (TPF - 1) * kTileR;
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_f32_kernel(const PropArgs
         const unsigned so0 = feat_src_off(wave), so1 = feat_src_off(wave + 8), so2 = feat_src_off(wave + 16),
                        so3 = feat_src_off(wave + 24), so4 = feat_src_off(32);
         auto stage = [&](int step, int buf) {
-            const int rt = r_lo + step;
-            const int n = rt / TPF, tile = rt - n * TPF;
+            const int rt = r_lo + step;               // pixel tile by pixel tile, the N frames inner (as prop_bf16.h)
+            const int tile = rt / N, n = rt - tile * N;
             const int slot = A.slot[n];
             unsigned char* lds = smem + buf * kF32Buf;
             const unsigned char* f = (const unsigned char*)A.feat_f32 + ((size_t)slot * A.HWp + (size_t)tile * kTileR) * kC * 4;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_f32_kernel(const PropArgs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
-        int cn = r_lo / TPF, ctile = r_lo - cn * TPF;
+        int ctile = r_lo / N, cn = r_lo - ctile * N;
         bool sparse = (A.sparse_mask >> cn) & 1ull;
         for (int p = 0; p < n_steps; ++p) {
             const unsigned char* lb = smem + (p & 1) * kF32Buf;
@@ -201,11 +202,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_f32_kernel(const PropArgs
                 st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ll0, o0, st.Y, 0, 0, 0);
                 st.Y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ll1, o1, st.Y, 0, 0, 0);
             }
-            if (++ctile == TPF) {
-                ctile = 0;
-                ++cn;
-                sparse = (A.sparse_mask >> cn) & 1ull;
+            if (++cn == N) {
+                cn = 0;
+                ++ctile;
             }
+            sparse = (A.sparse_mask >> cn) & 1ull;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile p + 1 have landed
             __syncthreads();
         }
