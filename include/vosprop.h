@@ -184,7 +184,7 @@ typedef struct vosprop_stats {
     int hw;                 /* H_d*W_d                                             */
     int workgroups;         /* grid of the propagation kernel                      */
     int tiles_per_wg;       /* reference tiles (32 rows) each workgroup walks      */
-    double flops;           /* algorithmic FLOP of the step: 2*N*HW^2*C + 2*d*N*HW^2 */
+    double flops;           /* algorithmic FLOP of the step, counted once: 2*N*HW^2*C + 2*d*N*HW^2 (top-k: + 2*d*k*HW) */
     double bytes;           /* algorithmic bytes: N*HW*C*2 + HW*C*2 + N*HW + d*HW*4   */
 } vosprop_stats;
 int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out);

@@ -498,7 +498,9 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     st.hw = ctx->HW;
     st.workgroups = lp.grid;
     st.tiles_per_wg = (int)(((long long)ctx->TT * n_ref * ctx->tiles + lp.grid - 1) / lp.grid);
-    st.flops = (topk ? 2.0 : 1.0) * 2.0 * n_ref * HW * HW * kC + (topk ? 0.0 : 2.0 * d * n_ref * HW * HW);   // top-k: 2 passes
+    // ALGORITHMIC work, counted once whatever the number of passes the implementation makes: the top-k
+    // variant scores every (reference, target) pair twice today, which is its cost, not its work
+    st.flops = 2.0 * n_ref * HW * HW * kC + (topk ? 2.0 * d * topk * HW : 2.0 * d * n_ref * HW * HW);
     st.bytes = n_ref * HW * kC * 2.0 + HW * kC * 2.0 + n_ref * HW + d * HW * 4.0;
     return VOSPROP_OK;
 }

@@ -84,6 +84,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// The same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset (saddr form): no 64-bit vector add per
+// piece, no VGPR pair.  M0 (the LDS destination) is set inside the statement and NOT restored: nothing else in the kernels that use
+// this form reads M0 (gfx950 LDS instructions do not), and hipcc sets M0 itself before any instruction of its own that needs it.
+__device__ __forceinline__ void glds16s(unsigned voff, const void* sbase, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 __device__ __forceinline__ float half_max(float x) {   // max(x[lane], x[lane ^ 32]) in every lane
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));

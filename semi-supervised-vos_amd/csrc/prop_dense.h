@@ -113,9 +113,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         third_lane = lane * 16;
         third_lds = kOffLabLo + (wave - 4) * 1024;
     }
+    third_tile_stride = __builtin_amdgcn_readfirstlane(third_tile_stride);
+    third_lds = __builtin_amdgcn_readfirstlane(third_lds);
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const unsigned smem_base = (unsigned)(size_t)(lds_ptr)smem;   // LDS byte address of the ring
-    const int slot_v = A.slot[lane];     // ring slot of sampled frame `lane` (kMaxRef = 64 = one per lane), read with v_readlane
+    // Per-frame source bases, one sampled frame per LANE (kMaxRef = 64): lane n holds the 64-bit address of frame n's features
+    // and of this wave's third piece in that frame.  A step fetches its two bases with four v_readlane and adds the tile offset -
+    // no per-piece 64-bit multiplies in the tile loop (the loop is issue-bound: every scalar instruction counts).
+    const size_t my_slot = (size_t)A.slot[lane];
+    const size_t fb = (size_t)A.feat_ring + my_slot * feat_slot_stride;
+    const size_t tb = (size_t)third_base + my_slot * third_slot_stride;
+    const unsigned fb_lo = (unsigned)fb, fb_hi = (unsigned)(fb >> 32), tb_lo = (unsigned)tb, tb_hi = (unsigned)(tb >> 32);
 
     const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
     for (int si = seg0; si < seg1; ++si) {
@@ -177,16 +185,20 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             stile = (r_lo + step) / N;
             sn = (r_lo + step) - stile * N;
         };
-        auto stage_piece = [&](int buf, int i) __attribute__((always_inline)) {
-            const unsigned lds = __builtin_amdgcn_readfirstlane(smem_base + (unsigned)(buf * kLdsBuf));
-            const int slot = __builtin_amdgcn_readlane(slot_v, sn);
-            if (i < 2) {
-                const unsigned char* f = (const unsigned char*)A.feat_ring + (size_t)slot * feat_slot_stride + (size_t)stile * kGlbFeat;
-                if (i == 0) glds16(f + src_a, lds + wave * 1024);
-                else glds16(f + src_b, lds + (wave + 8) * 1024);
-            } else {
-                glds16(third_base + (size_t)slot * third_slot_stride + (size_t)stile * third_tile_stride + third_lane, lds + third_lds);
-            }
+        // wave-uniform bases of the staging cursor's tile (set by stage_bases, used by the three pieces of a step)
+        const unsigned char *sb_feat = nullptr, *sb_third = nullptr;
+        auto stage_bases = [&]() __attribute__((always_inline)) {
+            const size_t f = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)fb_hi, sn) << 32) |
+                             (size_t)(unsigned)__builtin_amdgcn_readlane((int)fb_lo, sn);
+            const size_t t3 = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)tb_hi, sn) << 32) |
+                              (size_t)(unsigned)__builtin_amdgcn_readlane((int)tb_lo, sn);
+            sb_feat = (const unsigned char*)(f + (size_t)((unsigned)stile * (unsigned)kGlbFeat));
+            sb_third = (const unsigned char*)(t3 + (size_t)((unsigned)stile * third_tile_stride));
+        };
+        auto stage_piece = [&](unsigned lds, int i) __attribute__((always_inline)) {   // lds: LDS byte address of the target slot
+            if (i == 0) glds16s(src_a, sb_feat, lds + wave * 1024);
+            else if (i == 1) glds16s(src_b, sb_feat, lds + (wave + 8) * 1024);
+            else glds16s(third_lane, sb_third, lds + third_lds);
         };
         auto stage_advance = [&]() __attribute__((always_inline)) {   // next tile of the stream; stays on the last one at its end
             int nn = sn + 1, ns = stile;
@@ -204,9 +216,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         if (tid < 2 * kLdsLab / 16) *(f32x4*)(smem + 4 * kLdsBuf + kOffLabHi + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         stage_seek(0);
         for (int q = 0; q < 3; ++q) {   // prologue: tiles 0, 1, 2
-            stage_piece(q, 0);
-            stage_piece(q, 1);
-            stage_piece(q, 2);
+            stage_bases();
+            stage_piece(smem_base + q * kLdsBuf, 0);
+            stage_piece(smem_base + q * kLdsBuf, 1);
+            stage_piece(smem_base + q * kLdsBuf, 2);
             stage_advance();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -224,12 +237,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) S1[r] = -__builtin_inff();   // "tile -1": every probability 0 (whatever labels slot 4 holds)
         // ring slots of tile p (cur), p+1 (nxt), p-1 (prv), p+3 (stg): counters modulo 5
-        int s_cur = 0, s_nxt = 1, s_prv = 4, s_stg = 3;
+        // (kept as byte offsets into the ring)
+        int s_cur = 0, s_nxt = kLdsBuf, s_prv = 4 * kLdsBuf, s_stg = 3 * kLdsBuf;
         auto ring_advance = [&]() __attribute__((always_inline)) {
             s_prv = s_cur;
             s_cur = s_nxt;
-            s_nxt = s_nxt == 4 ? 0 : s_nxt + 1;
-            s_stg = s_stg == 4 ? 0 : s_stg + 1;
+            s_nxt = s_nxt == 4 * kLdsBuf ? 0 : s_nxt + kLdsBuf;
+            s_stg = s_stg == 4 * kLdsBuf ? 0 : s_stg + kLdsBuf;
         };
 
         // finish tile p-1: rescale check (rare), denominators, label MFMAs
@@ -255,9 +269,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 
         // one step: scores of tile p into S, softmax of tile p-1 (scores Sp, labels labp) in the gaps of the chain
         auto step = [&](f32x16& S, const f32x16& Sp) __attribute__((always_inline)) {
-            const unsigned char* lb = smem + s_cur * kLdsBuf;
-            const unsigned char* lbn = smem + s_nxt * kLdsBuf;
-            const int b_st = s_stg;
+            const unsigned char* lb = smem + s_cur;
+            const unsigned char* lbn = smem + s_nxt;
+            const unsigned b_st = smem_base + (unsigned)s_stg;
+            stage_bases();
             LabFrag<LAB_LO> labp;
             const float mc = st.m * c;
             float lt0 = 0.0f, lt1 = 0.0f, qprev = 0.0f;
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #if !(VOSPROP_DABLATE & 4)
                 if (ks == 2 || ks == 7 || ks == 12) stage_piece(b_st, ks / 5);
 #endif
-                if (ks == 10) labp.load(smem + s_prv * kLdsBuf, lane);   // labels of tile p-1, for the label MFMAs after the chain
+                if (ks == 10) labp.load(smem + s_prv, lane);   // labels of tile p-1, for the label MFMAs after the chain
                 // row ks of the previous tile
 #if VOSPROP_DABLATE & 1
                 const float q = Sp[ks];
@@ -366,7 +381,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             float lt0, lt1;
             bf16x8 pk0, pk1;
             LabFrag<LAB_LO> labp;
-            labp.load(smem + s_prv * kLdsBuf, lane);
+            labp.load(smem + s_prv, lane);
             softmax_rows<PROB>(Sp, Wt, c, st.m * c, lt0, lt1, pk0, pk1);
             finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
         };
