@@ -454,7 +454,8 @@ def main():
                        'encoder_dtype': args.encoder_dtype, 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
             'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us, 'end_to_end': end_to_end,
-            'roofline': {'kernel': 'prop_bf16_kernel', 'bound': 'mfma', 'achieved': achieved,
+            'roofline': {'kernel': 'prop_bf16_kernel<.,.,1> + <.,.,2> (top-k passes)' if wl['topk'] else 'prop_dense_kernel',
+                         'bound': 'mfma', 'achieved': achieved,
                          'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us,
                          'kernel_launches_timed': timed_launches, 'kernel_us_back_to_back': b2b_us, 'flops_per_launch': st['flops'],

@@ -117,13 +117,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
     third_lds = __builtin_amdgcn_readfirstlane(third_lds);
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const unsigned smem_base = (unsigned)(size_t)(lds_ptr)smem;   // LDS byte address of the ring
-    // Per-frame source bases, one sampled frame per LANE (kMaxRef = 64): lane n holds the 64-bit address of frame n's features
-    // and of this wave's third piece in that frame.  A step fetches its two bases with four v_readlane and adds the tile offset -
-    // no per-piece 64-bit multiplies in the tile loop (the loop is issue-bound: every scalar instruction counts).
-    const size_t my_slot = (size_t)A.slot[lane];
-    const size_t fb = (size_t)A.feat_ring + my_slot * feat_slot_stride;
-    const size_t tb = (size_t)third_base + my_slot * third_slot_stride;
-    const unsigned fb_lo = (unsigned)fb, fb_hi = (unsigned)(fb >> 32), tb_lo = (unsigned)tb, tb_hi = (unsigned)(tb >> 32);
+    // Per-frame source OFFSETS, one sampled frame per LANE (kMaxRef = 64): lane n holds the 32-bit byte offset of frame n inside the
+    // feature ring and inside this wave's third-piece array (both rings are far below 4 GiB).  The bases stay in two SGPR pairs for
+    // the whole kernel; a step fetches two offsets with v_readlane and adds the tile offset - no 64-bit arithmetic in the tile loop
+    // (the loop is issue-bound: 83 % of the SIMD's cycles issue an instruction, a quarter of them scalar).
+    const unsigned my_slot = (unsigned)A.slot[lane];
+    const unsigned fo = my_slot * (unsigned)feat_slot_stride;
+    const unsigned to = my_slot * (unsigned)third_slot_stride;
+    const unsigned char* const feat_base = (const unsigned char*)A.feat_ring;
 
     const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
     for (int si = seg0; si < seg1; ++si) {
@@ -185,20 +186,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             stile = (r_lo + step) / N;
             sn = (r_lo + step) - stile * N;
         };
-        // wave-uniform bases of the staging cursor's tile (set by stage_bases, used by the three pieces of a step)
-        const unsigned char *sb_feat = nullptr, *sb_third = nullptr;
+        // wave-uniform byte offsets of the staging cursor's tile (set by stage_bases, used by the three pieces of a step)
+        unsigned so_feat = 0, so_third = 0;
         auto stage_bases = [&]() __attribute__((always_inline)) {
-            const size_t f = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)fb_hi, sn) << 32) |
-                             (size_t)(unsigned)__builtin_amdgcn_readlane((int)fb_lo, sn);
-            const size_t t3 = ((size_t)(unsigned)__builtin_amdgcn_readlane((int)tb_hi, sn) << 32) |
-                              (size_t)(unsigned)__builtin_amdgcn_readlane((int)tb_lo, sn);
-            sb_feat = (const unsigned char*)(f + (size_t)((unsigned)stile * (unsigned)kGlbFeat));
-            sb_third = (const unsigned char*)(t3 + (size_t)((unsigned)stile * third_tile_stride));
+            so_feat = (unsigned)__builtin_amdgcn_readlane((int)fo, sn) + (unsigned)stile * (unsigned)kGlbFeat;
+            so_third = (unsigned)__builtin_amdgcn_readlane((int)to, sn) + (unsigned)stile * third_tile_stride;
         };
         auto stage_piece = [&](unsigned lds, int i) __attribute__((always_inline)) {   // lds: LDS byte address of the target slot
-            if (i == 0) glds16s(src_a, sb_feat, lds + wave * 1024);
-            else if (i == 1) glds16s(src_b, sb_feat, lds + (wave + 8) * 1024);
-            else glds16s(third_lane, sb_third, lds + third_lds);
+            if (i == 0) glds16s(src_a + so_feat, feat_base, lds + wave * 1024);
+            else if (i == 1) glds16s(src_b + so_feat, feat_base, lds + (wave + 8) * 1024);
+            else glds16s(third_lane + so_third, third_base, lds + third_lds);
         };
         auto stage_advance = [&]() __attribute__((always_inline)) {   // next tile of the stream; stays on the last one at its end
             int nn = sn + 1, ns = stile;
@@ -396,14 +393,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 
         // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
         float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + j;
+        int hh = h;
+        asm volatile("" : "+v"(part), "+v"(hh));   // row addresses are computed HERE: hoisted out of the segment loop as loop
+                                                    // invariants they were 22 registers spilled to scratch at kernel entry
         const float lsum = half_sum(st.l);
-        if (h == 0) {
+        if (hh == 0) {
             part[0] = st.m;
             part[kBT] = lsum;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int cls = acc_row(r, h);
+            const int cls = acc_row(r, hh);
             if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
         }
     }

@@ -14,4 +14,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_${tag}_$i -- python $R/tools/prop_bench.py --iters 5 "$@" > $R/gpurun_out/pmc_${tag}_$i.log 2>&1 || echo "pass $i failed"
 done
 python $R/tools/pmc_summary.py $R/gpurun_out/pmc_${tag}_[0-9] > $R/gpurun_out/pmc_${tag}_summary.txt 2>&1
+rm -rf $R/gpurun_out/pmc_${tag}_[0-9]
 cat $R/gpurun_out/pmc_${tag}_summary.txt

@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--iters', type=int, default=50)
     ap.add_argument('--scale', type=float, default=0.25)
     ap.add_argument('--prob', action='store_true')
+    ap.add_argument('--topk', type=int, default=0)
     ap.add_argument('--stateful', action='store_true', help='time the begin_video/step path (the dense one-hot kernel)')
     args = ap.parse_args()
     vos = importlib.import_module('semi-supervised-vos_amd')
@@ -34,7 +35,7 @@ def main():
     feats = (torch.randn(T, 256, Hd, Wd, generator=g) * args.scale).to(torch.bfloat16).to(dev)
     lab = torch.randint(0, args.d, (T, Hd * Wd), generator=g)
     oh = torch.zeros(args.d, T, Hd * Wd).scatter_(0, lab.unsqueeze(0), 1.0).to(dev)
-    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=args.ref_num, probability=args.prob)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=args.ref_num, probability=args.prob, topk=args.topk)
     if args.stateful:
         import numpy as np
         ann = np.zeros((Hd * 8, Wd * 8), np.uint8)

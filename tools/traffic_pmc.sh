@@ -1,25 +1,41 @@
 #!/bin/bash
-# HBM-side traffic of the shipped propagation kernel on the stateful path (the kernel bench.py's roofline line is about):
-# FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes, as MI355X_MICROARCH.md prescribes.  Writes
-# gpurun_out/traffic/summary.txt and .json (copy to profiles/).
+# HBM-side traffic of the propagation kernel(s) of one workload: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes, as
+# MI355X_MICROARCH.md prescribes (plus GRBM_GUI_ACTIVE, TCC hit / miss).  Usage (on the GPU box):
+#     bash tools/traffic_pmc.sh <tag> [prop_bench args]        e.g.  bash tools/traffic_pmc.sh davis480p_r50_dense --stateful
+# Writes gpurun_out/traffic_<tag>/{summary.txt,traffic.json} (copy the json to profiles/r02_prop_kernel_traffic_<tag>.json).
 R=$(cd "$(dirname "$0")/.." && pwd)
+tag=$1; shift
+O=$R/gpurun_out/traffic_$tag
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/traffic && mkdir -p $R/gpurun_out/traffic
+rm -rf $O && mkdir -p $O
 i=0
-for set in "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_GUI_ACTIVE WRITE_SIZE"; do
+for set in "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_GUI_ACTIVE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/traffic/p$i -- python $R/tools/prop_bench.py --stateful --iters 5 > $R/gpurun_out/traffic/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python $R/tools/prop_bench.py --iters 5 "$@" > $O/p$i.log 2>&1 || echo "pass $i failed"
 done
-python $R/tools/pmc_summary.py $R/gpurun_out/traffic/p1 $R/gpurun_out/traffic/p2 | tee $R/gpurun_out/traffic/summary.txt
-python - "$R/gpurun_out/traffic/summary.txt" <<'PY'
-import json, re, sys
-t = open(sys.argv[1]).read()
-f = float(re.search(r'FETCH_SIZE\s+n=\s*\d+ mean=([0-9.e+]+)', t).group(1))
-w = float(re.search(r'WRITE_SIZE\s+n=\s*\d+ mean=([0-9.e+]+)', t).group(1))
-# KiB -> bytes; FETCH_SIZE under-counts 16 B/lane streams by 2 on gfx950 (MI355X_MICROARCH.md, HBM section)
-out = {'kernel': 'prop_bf16_kernel<false,false,0>', 'workload': '480p map 60x107, N=9, d=4 (tools/prop_bench.py --stateful)',
-       'fetch_kib': f, 'write_kib': w, 'traffic_bytes_per_launch': 2 * f * 1024 + w * 1024,
-       'how': 'rocprofv3 --kernel-trace --pmc, FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950 wide-load correction)'}
+python $R/tools/pmc_summary.py $O/p1 $O/p2 $O/p3 | tee $O/summary.txt
+python - "$O/summary.txt" "$tag" "$*" <<'PY'
+import collections, json, re, sys
+rows = collections.defaultdict(dict)
+for ln in open(sys.argv[1]):
+    m = re.match(r'(\S+)\s+(\S+)\s+n=\s*\d+ mean=([0-9.e+-]+)', ln)
+    if m:
+        rows[m.group(1)][m.group(2)] = float(m.group(3))
+kern, tot, us = [], 0.0, 0.0
+for k, c in rows.items():
+    if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+        # KiB -> bytes; FETCH_SIZE under-counts 16 B/lane streams by 2 on gfx950 (MI355X_MICROARCH.md, HBM section)
+        b = 2 * c['FETCH_SIZE'] * 1024 + c['WRITE_SIZE'] * 1024
+        kern.append({'kernel': k, 'fetch_kib': c['FETCH_SIZE'], 'write_kib': c['WRITE_SIZE'], 'traffic_bytes': b,
+                     'kernel_us_profiled': c.get('kernel_us(profiled)'),
+                     'l2_hit_rate': c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']) if 'TCC_HIT_sum' in c else None})
+        tot += b
+        us += c.get('kernel_us(profiled)') or 0.0
+out = {'workload': sys.argv[2], 'bench_args': 'tools/prop_bench.py --iters 5 ' + sys.argv[3], 'kernels': kern,
+       'traffic_bytes_per_launch': tot, 'hbm_gb_per_s': tot / us / 1e3 if us else None,
+       'how': 'tools/traffic_pmc.sh: rocprofv3 --kernel-trace --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, mean of the last 6 '
+              'dispatches (full-N propagations); FETCH_SIZE x2 (gfx950: wide 16 B/lane streams are counted at half, '
+              'MI355X_MICROARCH.md HBM section); the propagation kernels of one step summed'}
 json.dump(out, open(sys.argv[1].replace('summary.txt', 'traffic.json'), 'w'), indent=1)
-print(out)
+print(json.dumps(out)[:600])
 PY
