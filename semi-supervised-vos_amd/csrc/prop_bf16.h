@@ -90,6 +90,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void glds16s(unsigned voff, const void* sbase, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// ... and with the two additions of a piece folded in (the tile loops are issue-bound, every instruction counts): M0 = lds_base +
+// lds_off in one scalar add, lane offset + wave-uniform byte offset in one vector add - which also is the wait state the hardware
+// wants between the M0 write and the LDS-DMA, so no s_nop.  Three instructions per piece.
+__device__ __forceinline__ void glds16s2(unsigned lane_off, unsigned soff, const void* sbase, unsigned lds_base, unsigned lds_off) {
+    unsigned vtmp;
+    asm volatile("s_add_u32 m0, %3, %4\n\tv_add_u32 %0, %1, %2\n\tglobal_load_lds_dwordx4 %0, %5"
+                 : "=&v"(vtmp)
+                 : "v"(lane_off), "s"(soff), "s"(lds_base), "s"(lds_off), "s"(sbase)
+                 : "memory", "scc");
+}
 
 __device__ __forceinline__ float half_max(float x) {   // max(x[lane], x[lane ^ 32]) in every lane
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);

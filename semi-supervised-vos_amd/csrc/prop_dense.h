@@ -192,10 +192,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             so_feat = (unsigned)__builtin_amdgcn_readlane((int)fo, sn) + (unsigned)stile * (unsigned)kGlbFeat;
             so_third = (unsigned)__builtin_amdgcn_readlane((int)to, sn) + (unsigned)stile * third_tile_stride;
         };
+        const unsigned lds_a = (unsigned)wave * 1024, lds_b = ((unsigned)wave + 8) * 1024;
         auto stage_piece = [&](unsigned lds, int i) __attribute__((always_inline)) {   // lds: LDS byte address of the target slot
-            if (i == 0) glds16s(src_a + so_feat, feat_base, lds + wave * 1024);
-            else if (i == 1) glds16s(src_b + so_feat, feat_base, lds + (wave + 8) * 1024);
-            else glds16s(third_lane + so_third, third_base, lds + third_lds);
+            if (i == 0) glds16s2(src_a, so_feat, feat_base, lds, lds_a);
+            else if (i == 1) glds16s2(src_b, so_feat, feat_base, lds, lds_b);
+            else glds16s2(third_lane, so_third, third_base, lds, third_lds);
         };
         auto stage_advance = [&]() __attribute__((always_inline)) {   // next tile of the stream; stays on the last one at its end
             int nn = sn + 1, ns = stile;
