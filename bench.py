@@ -38,7 +38,11 @@ WORKLOADS = {
     'davis480p_r50_top20_ref5': dict(H=480, W=854, ref_num=5, topk=20, model='resnet50'),
     'ytvos720p_r50_dense': dict(H=720, W=1280, ref_num=9, topk=0, model='resnet50'),
     'pair240p_r18': dict(H=240, W=427, ref_num=9, topk=0, model='resnet18'),
+    # BASELINE.json configs[4], second reading ("HBM-bandwidth stress"): the (N HW) x HW affinity written to HBM as bf16 and read
+    # back, as the reference's own algorithm does (src/model/predict.py:49-55); its roofline is HBM, not MFMA
+    'ytvos720p_r50_dense_materialised': dict(H=720, W=1280, ref_num=9, topk=0, model='resnet50', materialise=True),
 }
+HBM_PEAK_GBS = 8000.0                # /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW" (spec; ~6.3 TB/s achievable)
 
 
 def synthetic_clip(H, W, n_frames, seed, device):
@@ -323,7 +327,7 @@ def main():
     clip = clip.to(enc_dtype).contiguous(memory_format=torch.channels_last)
     eng = vos.PropagationEngine(Hd, Wd, device=local, ref_num=wl['ref_num'], frame_range=cfg['frame_range'],
                                 sigma1=cfg['sigma1'], sigma2=cfg['sigma2'], temperature=cfg['temperature'],
-                                topk=wl['topk'])
+                                topk=wl['topk'], materialise=wl.get('materialise', False))
     eng.begin_video(ann)
 
     keep_feats, keep_cls, keep_masks = [], [], []
@@ -397,6 +401,8 @@ def main():
     if not timed_launches:                                # top-k runs two passes + a selection: only the back-to-back timer covers it
         prop_us = b2b_us
     achieved = st['flops'] / (prop_us * 1e-6) / 1e12
+    hbm_bound = bool(wl.get('materialise'))          # the materialised-affinity variant is priced against the HBM roof
+    achieved_gbs = st['bytes'] / (prop_us * 1e-6) / 1e9
     # propagation-only frames/s (push + propagate + combine + label pack + mask), encoder excluded
     with torch.no_grad():
         feats = net(clip[0:1]).detach()
@@ -424,7 +430,7 @@ def main():
     # ---- end to end, host to host: uint8 frames in pinned host memory -> H2D -> normalise -> encoder ->
     # propagate -> mask -> D2H into pinned host memory.  Reported beside `value`, never as `value`.
     end_to_end = None
-    if not args.no_end_to_end and wl['topk'] == 0:
+    if not args.no_end_to_end and wl['topk'] == 0 and not wl.get('materialise'):
         end_to_end = end_to_end_leg(args, wl, dev, clip, pool, net, eng, enc_dtype, fence, world, on_gloo)
 
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them, in
@@ -454,9 +460,11 @@ def main():
                        'encoder_dtype': args.encoder_dtype, 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
             'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us, 'end_to_end': end_to_end,
-            'roofline': {'kernel': 'prop_bf16_kernel<.,.,1> + <.,.,2> (top-k passes)' if wl['topk'] else 'prop_dense_kernel',
-                         'bound': 'mfma', 'achieved': achieved,
-                         'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / MFMA_BF16_PEAK_TFLOPS,
+            'roofline': {'kernel': ('prop_dense_kernel<.,.,1> + <.,.,2> (affinity out to HBM, then back)' if hbm_bound else
+                                    'prop_bf16_kernel<.,.,1> + <.,.,2> (top-k passes)' if wl['topk'] else 'prop_dense_kernel'),
+                         'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': achieved_gbs if hbm_bound else achieved,
+                         'peak': HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TFLOPS, 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+                         'frac': achieved_gbs / HBM_PEAK_GBS if hbm_bound else achieved / MFMA_BF16_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us,
                          'kernel_launches_timed': timed_launches, 'kernel_us_back_to_back': b2b_us, 'flops_per_launch': st['flops'],
                          'algorithmic_bytes_per_launch': st['bytes'], 'workgroups': st['workgroups'], 'pmc': pmc},

@@ -73,7 +73,11 @@ typedef struct vosprop_config {
                              no renormalisation (NOT in the reference; label-propagation mode only; two kernel passes) */
     int precision;        /* VOSPROP_PREC_*                                                      */
     int ring_capacity;    /* 0 = auto: max(frame_range + 4, ref_num) + 1 frames; anything smaller is VOSPROP_E_INVALID */
-    int reserved[8];      /* zero                                                                */
+    int materialise;      /* 0 = fused (nothing of size (H_d W_d)^2 touches HBM).  1 = the reference's algorithm SHAPE
+                             (src/model/predict.py:49-55): the (N HW) x HW affinity is written to HBM as bf16 and read back -
+                             2 x N HW^2 x 2 bytes per step (7.46 GB at 720p), an HBM-bandwidth-bound variant kept for measurement
+                             (BASELINE.json configs[4]); dense, bf16 path only.  (Was reserved[0]: old callers pass 0.)          */
+    int reserved[7];      /* zero                                                                */
 } vosprop_config;
 
 /* Fill cfg with the reference CLI defaults for a (feat_h, feat_w) map. */

@@ -79,7 +79,7 @@ def feature_map_size(H, W):
 
 
 def predict(ref, target, ref_label, weight_dense, weight_sparse, frame_idx, take_range, ref_num,
-            temperature, probability_propagation, topk=0):
+            temperature, probability_propagation, topk=0, affinity_bf16=False):
     """src/model/predict.py:19-71, op for op.
 
     ref (T,C,H,W) f32; target (C,H,W); ref_label (d,T,HW); weights (HW,HW) or None.
@@ -98,6 +98,10 @@ def predict(ref, target, ref_label, weight_dense, weight_sparse, frame_idx, take
     R = ref_sel.permute(0, 2, 3, 1).reshape(-1, C)
     T = target.reshape(C, -1)
     S = R.mm(T)
+    if affinity_bf16:
+        # NOT the reference's CPU path: the affinity as the engine's materialised variant keeps it in HBM (bf16; the reference's
+        # CUDA autocast path keeps it in fp16) - checker of tests/test_gpu_configs.py::test_config5_materialised_affinity
+        S = S.to(torch.bfloat16).to(torch.float32)
     S *= temperature
     S = S.softmax(dim=0)
     S = S.contiguous().view(num_ref, H * W, H * W)
@@ -129,7 +133,7 @@ def spatial_weight_columns(shape, sigma, cols):
 
 
 def predict_columns(ref, target, ref_label, sigma1, sigma2, frame_idx, take_range, ref_num, temperature,
-                    probability_propagation, cols, topk=0):
+                    probability_propagation, cols, topk=0, affinity_bf16=False):
     """`predict` restricted to the target pixels `cols`: returns predict(...)[:, cols].  Every target pixel is an independent
     column of the reference's computation (mm column, softmax over dim 0, weight column, label mm column; predict.py:49-70), so
     the full-size BASELINE configs (720p: a 7.5 GB f32 affinity, three times) can be checked on a few hundred columns in
@@ -146,6 +150,8 @@ def predict_columns(ref, target, ref_label, sigma1, sigma2, frame_idx, take_rang
     R = ref_sel.permute(0, 2, 3, 1).reshape(-1, C)
     T = target.reshape(C, -1)[:, cols].contiguous()
     S = R.mm(T)
+    if affinity_bf16:
+        S = S.to(torch.bfloat16).to(torch.float32)
     S *= temperature
     S = S.softmax(dim=0)
     S = S.contiguous().view(num_ref, H * W, cols.numel())

@@ -25,7 +25,8 @@ class Config(ctypes.Structure):
                 ('feat_w', ctypes.c_int), ('channels', ctypes.c_int), ('ref_num', ctypes.c_int),
                 ('frame_range', ctypes.c_int), ('sigma1', ctypes.c_float), ('sigma2', ctypes.c_float),
                 ('temperature', ctypes.c_float), ('probability', ctypes.c_int), ('topk', ctypes.c_int),
-                ('precision', ctypes.c_int), ('ring_capacity', ctypes.c_int), ('reserved', ctypes.c_int * 8)]
+                ('precision', ctypes.c_int), ('ring_capacity', ctypes.c_int), ('materialise', ctypes.c_int),
+                ('reserved', ctypes.c_int * 7)]
 
 
 class Stats(ctypes.Structure):

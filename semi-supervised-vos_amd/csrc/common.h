@@ -71,6 +71,7 @@ struct PropArgs {
     const bf16_t* coord_tab;    // [HWp/32][2][32][8]    reference-side spatial channels
     const bf16_t* lab_hi;       // [cap][HWp/32][2][64][8] labels in MFMA A-operand order (hi part)
     const bf16_t* lab_lo;       // same, low part (probability mode) or nullptr
+    bf16_t* smat;               // materialised-affinity variant only: [N * tiles][column blocks][64][16] bf16 score tiles
     float* part;                // [n_segments][part_rows][kBT]  per-segment partial (m, l, numerators)
     int slot[kMaxRef];          // ring slot of each sampled reference frame
     unsigned long long sparse_mask;   // bit n set: frame n uses sigma2 (the "interval" frames)

@@ -39,6 +39,7 @@ struct LastProp {
     PropArgs args;        // dense: the launch; top-k: pass 2 (pass 1 differs in part_rows only)
     int grid = 0;
     bool prob = false, lab_lo = false;
+    bool materialise = false;
     int topk = 0;
     int rows_pass1 = 0;
     const int* d_off = nullptr;    // plan lists (top-k select between the passes)
@@ -69,6 +70,8 @@ struct vosprop_ctx {
     float2* coord_f32 = nullptr;   // [HWp] the reference's f32 pixel coordinates (f32 path)
     float* part = nullptr;
     size_t part_bytes = 0;
+    bf16_t* smat = nullptr;        // materialised-affinity variant: score tiles in HBM (grown on demand)
+    size_t smat_bytes = 0;
     float* pred_buf = nullptr;     // (kMaxClasses, HW) f32
     uint8_t* cls_tmp = nullptr;    // (HWp)
     uint8_t* stage_host = nullptr; // pinned (HWp): first labels of a video on their way to the GPU (stream-ordered upload)
@@ -359,6 +362,17 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream
     // dense path: the in-wave pipelined kernel (prop_dense.h).  VOSPROP_DENSE_TWO_BURST=1 selects the round-1 two-burst schedule of
     // prop_bf16.h (same results; A/B timing only)
     static const bool two_burst = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
+    if (lp.materialise) {   // the materialised-affinity variant: score tiles out to HBM, then back in (prop_dense.h MAT 1 / 2)
+        if (lp.prob) {
+            hipLaunchKernelGGL((prop_dense_kernel<true, true, 1>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((prop_dense_kernel<true, true, 2>), grid, block, 0, s, a);
+        } else {
+            hipLaunchKernelGGL((prop_dense_kernel<false, false, 1>), grid, block, 0, s, a);
+            if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<false, true, 2>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((prop_dense_kernel<false, false, 2>), grid, block, 0, s, a);
+        }
+        return;
+    }
     if (!two_burst) {
         if (lp.prob) {
             if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<true, true>), grid, block, 0, s, a);
@@ -446,11 +460,25 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     if (rc) return rc;
     a.part = ctx->part;
     a.part_rows = topk ? 2 : 2 + d;
+    lp.materialise = ctx->cfg.materialise != 0;
+    if (lp.materialise) {
+        if (f32 || topk) return fail(ctx, VOSPROP_E_UNSUPPORTED, "the materialised-affinity variant is dense, bf16 path only");
+        const size_t need = (size_t)n_ref * ctx->tiles * ((size_t)ctx->TT * kWaves) * 64 * 16 * sizeof(bf16_t);
+        if (need > ctx->smat_bytes) {
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            if (ctx->smat) (void)hipFree(ctx->smat);
+            ctx->smat = nullptr;
+            ctx->smat_bytes = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->smat, need));
+            ctx->smat_bytes = need;
+        }
+        a.smat = ctx->smat;
+    }
     a.tk_thr = ctx->tk_thr;
     a.tk_m = ctx->tk_m;
     a.tk_cnt = ctx->tk_cnt;
     a.tk_cand = ctx->tk_cand;
-    const bool timed = ctx->timing && !f32 && !topk && !prob && !lab_lo && ctx->tev_used + 2 <= 2 * 4096;
+    const bool timed = ctx->timing && !f32 && !topk && !prob && !lab_lo && !lp.materialise && ctx->tev_used + 2 <= 2 * 4096;
     if (timed) {
         while (ctx->tev.size() < ctx->tev_used + 2) {
             hipEvent_t e;
@@ -502,6 +530,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     // variant scores every (reference, target) pair twice today, which is its cost, not its work
     st.flops = 2.0 * n_ref * HW * HW * kC + (topk ? 2.0 * d * topk * HW : 2.0 * d * n_ref * HW * HW);
     st.bytes = n_ref * HW * kC * 2.0 + HW * kC * 2.0 + n_ref * HW + d * HW * 4.0;
+    if (lp.materialise) st.bytes += 2.0 * n_ref * HW * HW * 2.0;   // the bf16 affinity written once and read once
     return VOSPROP_OK;
 }
 
@@ -701,6 +730,7 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
     if (cfg->precision == VOSPROP_PREC_F32 && cfg->topk != 0) return VOSPROP_E_UNSUPPORTED;   // top-k: bf16 path only
     if (cfg->topk < 0 || cfg->topk > kTopkMax) return VOSPROP_E_UNSUPPORTED;
     if (cfg->topk != 0 && cfg->probability) return VOSPROP_E_UNSUPPORTED;
+    if (cfg->materialise && (cfg->topk != 0 || cfg->precision != VOSPROP_PREC_BF16)) return VOSPROP_E_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || cfg->device < 0 || cfg->device >= ndev) return VOSPROP_E_HIP;
     if (hipSetDevice(cfg->device) != hipSuccess) return VOSPROP_E_HIP;
@@ -746,6 +776,7 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     if (ctx->coord_f32) (void)hipFree(ctx->coord_f32);
     if (ctx->up_tab) (void)hipFree(ctx->up_tab);
     if (ctx->part) (void)hipFree(ctx->part);
+    if (ctx->smat) (void)hipFree(ctx->smat);
     for (Plan& p : ctx->plans) {
         if (p.d_off) (void)hipFree(p.d_off);
         if (p.d_list) (void)hipFree(p.d_list);

@@ -58,7 +58,12 @@ __device__ __forceinline__ void softmax_rows(const f32x16& Sp, const float (&Wt)
     }
 }
 
-template <bool PROB, bool LAB_LO>
+// MAT: 0 = the fused kernel.  1 / 2 = the two halves of the MATERIALISED-affinity variant (BASELINE.json configs[4], "HBM-bandwidth
+// stress"; the shape of the reference's own algorithm, src/model/predict.py:49-55, which writes the (N HW) x HW affinity to memory
+// and reads it back): MAT 1 runs only the score MFMAs and stores every 32 x 32 score tile to HBM as bf16 (64 lanes x 32 B,
+// accumulator order), MAT 2 runs everything EXCEPT the score MFMAs and takes the score tiles back from HBM (two LDS-DMA pieces per
+// wave and step in place of the two feature pieces).  2 x N HW^2 x 2 B of traffic per step: 7.46 GB at 720p.
+template <bool PROB, bool LAB_LO, int MAT = 0>
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropArgs A) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kRing5 * kLdsBuf];
     __shared__ __attribute__((aligned(16))) bf16x8 s_bx[2][kWaves * 64];   // per-lane prior constants (see prop_bf16.h)
@@ -113,6 +118,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         third_lane = lane * 16;
         third_lds = kOffLabLo + (wave - 4) * 1024;
     }
+    // MAT 2: the first 16 KiB of a slot hold the eight waves' score tiles, not features: the waves without a third piece of their
+    // own (and wave 0's feature piece 16) aim their third piece at the KiB of slack behind them
+    if (MAT == 2 && third_base == (const unsigned char*)A.feat_ring) third_lds = 16 * 1024;
     third_tile_stride = __builtin_amdgcn_readfirstlane(third_tile_stride);
     third_lds = __builtin_amdgcn_readfirstlane(third_lds);
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -192,9 +200,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             so_feat = (unsigned)__builtin_amdgcn_readlane((int)fo, sn) + (unsigned)stile * (unsigned)kGlbFeat;
             so_third = (unsigned)__builtin_amdgcn_readlane((int)to, sn) + (unsigned)stile * third_tile_stride;
         };
-        const unsigned lds_a = (unsigned)wave * 1024, lds_b = ((unsigned)wave + 8) * 1024;
+        const unsigned lds_a = MAT == 2 ? (unsigned)wave * 2048 : (unsigned)wave * 1024;
+        const unsigned lds_b = MAT == 2 ? (unsigned)wave * 2048 + 1024 : ((unsigned)wave + 8) * 1024;
+        // MAT 1 / 2: this wave's score tiles in HBM: smat[stream index][column block][lane][16 bf16]
+        const size_t mat_cb = (size_t)tt * kWaves + wave;                        // column block of 32 target pixels
+        const size_t mat_blocks = (size_t)((A.HWp + kBT - 1) / kBT) * kWaves;    // column blocks per stream index
         auto stage_piece = [&](unsigned lds, int i) __attribute__((always_inline)) {   // lds: LDS byte address of the target slot
-            if (i == 0) glds16s2(src_a, so_feat, feat_base, lds, lds_a);
+            if (MAT == 2 && i < 2) {
+                const int rs = stile * N + sn;      // stream index of the staged tile
+                const unsigned char* src = (const unsigned char*)A.smat + (((size_t)rs * mat_blocks + mat_cb) * 64 + lane) * 32 + i * 16;
+                glds16(src, lds + (i ? lds_b : lds_a));
+            } else if (i == 0) glds16s2(src_a, so_feat, feat_base, lds, lds_a);
             else if (i == 1) glds16s2(src_b, so_feat, feat_base, lds, lds_b);
             else glds16s2(third_lane, so_third, third_base, lds, third_lds);
         };
@@ -229,7 +245,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         bool need_w = !PROB;
 
         AFrag<PROB> fr;
-        fr.prefetch(smem, j, h);
+        if (MAT != 2) fr.prefetch(smem, j, h);
+        int crs = r_lo;     // stream index of the tile being scored (MAT 1: where its score tile goes)
 
         f32x16 S0, S1;
 #pragma unroll
@@ -279,21 +296,29 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             const unsigned char* nrow = lbn + j * kRowB + h * 16;
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+            bf16x8 sm0, sm1;
+            if (MAT == 2) {      // this wave's score tile of tile p, landed in the slot's first 16 KiB two steps ago
+                sm0 = *(const bf16x8*)(lb + wave * 2048 + lane * 16);
+                sm1 = *(const bf16x8*)(lb + wave * 2048 + 1024 + lane * 16);
+            }
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
+                if (MAT != 2) {
 #if VOSPROP_DABLATE & 16
-                asm volatile("" : "+v"(fr.a[ks & 7]));
+                    asm volatile("" : "+v"(fr.a[ks & 7]));
 #else
-                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[ks & 7], Bt[ks], S, 0, 0, 0);
+                    S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[ks & 7], Bt[ks], S, 0, 0, 0);
 #endif
-                // refill the fragment slot just consumed: second half of this tile, then the first half of the next one
+                    // refill the fragment slot just consumed: second half of this tile, then the first half of the next one
 #if !(VOSPROP_DABLATE & 2)
-                if (ks < 8) fr.a[ks] = *(const bf16x8*)(arow + (ks + 8) * 32);
-                else fr.a[ks - 8] = *(const bf16x8*)(nrow + (ks - 8) * 32);
+                    if (ks < 8) fr.a[ks] = *(const bf16x8*)(arow + (ks + 8) * 32);
+                    else fr.a[ks - 8] = *(const bf16x8*)(nrow + (ks - 8) * 32);
 #endif
+                }
 #if !(VOSPROP_DABLATE & 4)
                 if (ks == 2 || ks == 7 || ks == 12) stage_piece(b_st, ks / 5);
 #endif
+                if (MAT == 1) continue;                        // score tiles only
                 if (ks == 10) labp.load(smem + s_prv, lane);   // labels of tile p-1, for the label MFMAs after the chain
                 // row ks of the previous tile
 #if VOSPROP_DABLATE & 1
@@ -334,9 +359,28 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             }
             // the packed weights are "used" here, in the chain's basic block: hipcc otherwise sinks the multiplies and packings of the
             // fast path below the rescale branch, out of the MFMA shadow
-            asm volatile("" : "+v"(pk0), "+v"(pk1));
+            if (MAT != 1) asm volatile("" : "+v"(pk0), "+v"(pk1));
             stage_advance();
-            finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
+            if (MAT != 1) finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
+            if (MAT == 2) {      // the scores of tile p as they came back from HBM (bf16: the materialised affinity's precision)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    S[e] = (float)sm0[e];
+                    S[8 + e] = (float)sm1[e];
+                }
+            }
+            if (MAT == 1) {      // the score tile goes to HBM: 64 lanes x 32 B, accumulator order
+                bf16x8 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o0[e] = (bf16_t)S[e];
+                    o1[e] = (bf16_t)S[8 + e];
+                }
+                bf16_t* dst = A.smat + (((size_t)crs * mat_blocks + mat_cb) * 64 + lane) * 16;
+                __builtin_nontemporal_store(o0, (bf16x8*)dst);
+                __builtin_nontemporal_store(o1, (bf16x8*)(dst + 8));
+            }
+            ++crs;
             // tile p: padded rows of a frame's last tile never enter the softmax (wave-uniform, rare)
             if (ragged && ctile == TPF - 1) {
                 asm volatile("; tail tile" ::: "memory");
@@ -362,10 +406,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             }
             // this wave's pieces of tile p+2 have landed (the 3 of tile p+3 may stay in flight); the barrier then makes every
             // wave's pieces of p+2 visible and retires slot (p & 3) for the DMA of step p+1
-            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if (MAT == 1) {
+                // the score-tile stores are counted by hipcc: a __syncthreads() here would drain them every step.  Own LDS-DMA
+                // pieces of tile p+2: all but the 3 pieces and 2 stores issued in this step
+                asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 #if !(VOSPROP_DABLATE & 8)
-            __syncthreads();
+                __syncthreads();
 #endif
+            }
             ring_advance();
         };
 
@@ -385,13 +435,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         };
         if (p < n_steps) {
             step(S0, S1);
-            drain(S0);
+            if (MAT != 1) drain(S0);
         } else {
-            drain(S1);
+            if (MAT != 1) drain(S1);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the look-ahead pieces before the ring is re-staged
         __syncthreads();
 
+        if (MAT == 1) continue;
         // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
         float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + j;
         int hh = h;

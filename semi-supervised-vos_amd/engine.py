@@ -33,7 +33,7 @@ class PropagationEngine:
     """
 
     def __init__(self, feat_h, feat_w, device=None, ref_num=9, frame_range=40, sigma1=8.0, sigma2=21.0,
-                 temperature=1.0, probability=False, topk=0, precision=PREC_BF16, ring_capacity=0):
+                 temperature=1.0, probability=False, topk=0, precision=PREC_BF16, ring_capacity=0, materialise=False):
         L = _native.lib()
         if not torch.cuda.is_available():
             raise VospropError('no HIP device visible: the propagation engine has no CPU path')
@@ -46,6 +46,7 @@ class PropagationEngine:
         cfg.sigma1, cfg.sigma2, cfg.temperature = float(sigma1), float(sigma2), float(temperature)
         cfg.probability, cfg.topk, cfg.precision = int(bool(probability)), int(topk), int(precision)
         cfg.ring_capacity = int(ring_capacity)
+        cfg.materialise = int(bool(materialise))
         self.cfg = cfg
         self._L = L
         self._ctx = ctypes.c_void_p()

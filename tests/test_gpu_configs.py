@@ -160,6 +160,35 @@ def test_config5_720p_rollout_through_step(vos, dev):
     eng.close()
 
 
+@pytest.mark.parametrize('Hd,Wd,prob', [(12, 20, False), (17, 19, True), (90, 160, False)])
+def test_config5_materialised_affinity(vos, dev, Hd, Wd, prob):
+    """configs[4], the HBM-stress variant: the engine writes the (N HW) x HW affinity to HBM as bf16 and reads it back (the shape of
+    the reference's own algorithm, src/model/predict.py:49-55; 7.46 GB per step at 90x160).  Checked against the oracle with its
+    affinity rounded to bf16 at the same point, and against the fused engine: same masks wherever the margin is clear."""
+    T, d, fi = 21, 4, 20
+    feats, oh = random_case(77 + Hd, Hd, Wd, T, d)
+    HW = Hd * Wd
+    cols = some_columns(HW, 6, n_random=256) if HW > 2000 else np.arange(HW)
+    fd, ld = torch.from_numpy(feats).to(dev), torch.from_numpy(oh).to(dev)
+    em = vos.PropagationEngine(Hd, Wd, device=0, materialise=True)
+    ef = vos.PropagationEngine(Hd, Wd, device=0)
+    got = em.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 40, 9, 1.0, 8.0, 21.0, prob).cpu().numpy()
+    fused = ef.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 40, 9, 1.0, 8.0, 21.0, prob).cpu().numpy()
+    want = vo.predict_columns(feats[:fi], feats[fi], oh[:, :fi], 8.0, 21.0, fi, 40, 9, 1.0, prob, cols, affinity_bf16=True).numpy()
+    # a score that sits on a bf16 rounding boundary can round the other way in the engine (f32 sums in MFMA order): one such
+    # element moves its probability by 2^(2^-8 |s| c) - 1; the tolerance is per column total, not per element
+    colsum = want.sum(0, keepdims=True)
+    assert np.all(np.abs(got[:, cols] - want) <= 1e-2 * np.maximum(colsum, 1e-6) + 1e-6), float(np.max(np.abs(got[:, cols] - want) / np.maximum(colsum, 1e-6)))
+    srt = np.sort(fused, axis=0)
+    clear = (srt[-1] - srt[-2]) > 5e-2 * srt[-1]
+    assert clear.sum() > 50 and np.all(got.argmax(0)[clear] == fused.argmax(0)[clear])
+    st = em.last_stats()
+    assert st['bytes'] > 2.0 * 9 * HW * HW * 2.0            # the stats price the written + re-read affinity
+    em.close(); ef.close()
+    with pytest.raises(vos.VospropError):
+        vos.PropagationEngine(Hd, Wd, device=0, materialise=True, topk=5)
+
+
 def _davis_like_dataset(root, lengths, H=64, W=96):
     from PIL import Image
     case = dict(gin.ROLLOUT_CASES[0], image_hw=(H, W))

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--scale', type=float, default=0.25)
     ap.add_argument('--prob', action='store_true')
     ap.add_argument('--topk', type=int, default=0)
+    ap.add_argument('--materialise', action='store_true', help='the materialised-affinity (HBM-stress) variant')
     ap.add_argument('--stateful', action='store_true', help='time the begin_video/step path (the dense one-hot kernel)')
     args = ap.parse_args()
     vos = importlib.import_module('semi-supervised-vos_amd')
@@ -35,7 +36,8 @@ def main():
     feats = (torch.randn(T, 256, Hd, Wd, generator=g) * args.scale).to(torch.bfloat16).to(dev)
     lab = torch.randint(0, args.d, (T, Hd * Wd), generator=g)
     oh = torch.zeros(args.d, T, Hd * Wd).scatter_(0, lab.unsqueeze(0), 1.0).to(dev)
-    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=args.ref_num, probability=args.prob, topk=args.topk)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=args.ref_num, probability=args.prob, topk=args.topk,
+                                materialise=args.materialise)
     if args.stateful:
         import numpy as np
         ann = np.zeros((Hd * 8, Wd * 8), np.uint8)
@@ -50,6 +52,7 @@ def main():
     us = eng.time_last_propagation(args.iters)
     st = eng.last_stats()
     print(json.dumps({'kernel_us': us, 'tflops': st['flops'] / us / 1e6, 'frac_of_2500': st['flops'] / us / 1e6 / 2500,
+                      'algorithmic_gb_per_s': st['bytes'] / us / 1e3,
                       'workgroups': st['workgroups'], 'tiles_per_wg': st['tiles_per_wg'], 'n_ref': st['n_ref'],
                       'hw': st['hw'], 'checksum': float(out.sum())}))
     L = vos._native.lib()
