@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--prob', action='store_true')
     ap.add_argument('--topk', type=int, default=0)
     ap.add_argument('--materialise', action='store_true', help='the materialised-affinity (HBM-stress) variant')
+    ap.add_argument('--f32', action='store_true', help='the f32 parity path (VOSPROP_PREC_F32)')
     ap.add_argument('--stateful', action='store_true', help='time the begin_video/step path (the dense one-hot kernel)')
     args = ap.parse_args()
     vos = importlib.import_module('semi-supervised-vos_amd')
@@ -33,11 +34,11 @@ def main():
     Hd, Wd, fi = args.hd, args.wd, 20
     T = fi + 1
     g = torch.Generator(device='cpu').manual_seed(0)
-    feats = (torch.randn(T, 256, Hd, Wd, generator=g) * args.scale).to(torch.bfloat16).to(dev)
+    feats = (torch.randn(T, 256, Hd, Wd, generator=g) * args.scale).to(torch.float32 if args.f32 else torch.bfloat16).to(dev)
     lab = torch.randint(0, args.d, (T, Hd * Wd), generator=g)
     oh = torch.zeros(args.d, T, Hd * Wd).scatter_(0, lab.unsqueeze(0), 1.0).to(dev)
     eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=args.ref_num, probability=args.prob, topk=args.topk,
-                                materialise=args.materialise)
+                                materialise=args.materialise, precision=1 if args.f32 else 0)
     if args.stateful:
         import numpy as np
         ann = np.zeros((Hd * 8, Wd * 8), np.uint8)
