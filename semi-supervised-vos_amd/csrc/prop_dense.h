@@ -239,6 +239,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
+        STAMP_DECL;
+#ifdef VOSPROP_STAMP
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
         // compute cursor (pixel tile, frame) of the tile whose SCORES are being computed
         int ctile = r_lo / N, cn = r_lo - ctile * N;
         bool sparse = (A.sparse_mask >> cn) & 1ull;
@@ -301,8 +305,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 sm0 = *(const bf16x8*)(lb + wave * 2048 + lane * 16);
                 sm1 = *(const bf16x8*)(lb + wave * 2048 + 1024 + lane * 16);
             }
+#ifdef VOSPROP_STAMP
+            STAMP_AT(0);   // 0: step head (cursor offsets, accumulator zeroing) + whatever the previous step left
+#endif
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
+#ifdef VOSPROP_STAMP
+                if (ks == 8) STAMP_AT(1);   // 1: gaps 0-7
+#endif
                 if (MAT != 2) {
 #if VOSPROP_DABLATE & 16
                     asm volatile("" : "+v"(fr.a[ks & 7]));
@@ -360,8 +370,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             // the packed weights are "used" here, in the chain's basic block: hipcc otherwise sinks the multiplies and packings of the
             // fast path below the rescale branch, out of the MFMA shadow
             if (MAT != 1) asm volatile("" : "+v"(pk0), "+v"(pk1));
+#ifdef VOSPROP_STAMP
+            STAMP_AT(2);   // 2: gaps 8-15
+#endif
             stage_advance();
             if (MAT != 1) finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
+#ifdef VOSPROP_STAMP
+            STAMP_AT(3);   // 3: rescale check + label MFMAs
+#endif
             if (MAT == 2) {      // the scores of tile p as they came back from HBM (bf16: the materialised affinity's precision)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -411,9 +427,18 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 // pieces of tile p+2: all but the 3 pieces and 2 stores issued in this step
                 asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             } else {
+#ifdef VOSPROP_STAMP
+                STAMP_AT(4);   // 4: tail mask, prior tile, cursor
+#endif
                 asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#ifdef VOSPROP_STAMP
+                STAMP_AT(5);   // 5: wait for the own pieces of tile p+2
+#endif
 #if !(VOSPROP_DABLATE & 8)
                 __syncthreads();
+#endif
+#ifdef VOSPROP_STAMP
+                STAMP_AT(6);   // 6: barrier
 #endif
             }
             ring_advance();
@@ -441,6 +466,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the look-ahead pieces before the ring is re-staged
         __syncthreads();
+#ifdef VOSPROP_STAMP
+        if (A.dbg && lane == 0)
+            for (int k = 0; k < VOSPROP_NSTAMP; ++k)
+                atomicAdd(&A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + k], tsum[k]);
+#endif
 
         if (MAT == 1) continue;
         // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----

@@ -68,8 +68,8 @@ def main():
         assert got == n, got
         a = buf.reshape(-1, 8, NS).astype(np.float64) / st['tiles_per_wg']
         names = ['loop', 'ld-issue', 'mfma', 'bar1', 'prefetch', 'max', 'exp', 'labmfma', 'stwrite', 'bar2']
-        if os.environ.get('VOSPROP_V6'):
-            names = ['pre', 'chain0', 'chain1', 'post', 'dmawait', 'barrier']
+        if not os.environ.get('VOSPROP_DENSE_TWO_BURST') and not args.topk:
+            names = ['head', 'gaps0-7', 'gaps8-15', 'check+labmfma', 'tail+prior', 'dmawait', 'barrier']
         print('stamps: cycles per tile')
         for g, sl in (('A (waves 0-3)', slice(0, 4)), ('B (waves 4-7)', slice(4, 8))):
             m = a[:, sl].mean((0, 1))
