@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace vosprop {
 
@@ -91,6 +92,7 @@ struct PropArgs {
     const float* tk_m;          // [HWp] pass 2: column max of the raw scores (exact softmax max, from pass 1)
     unsigned* tk_cnt;           // [HWp] pass 2: number of candidates appended per target pixel
     uint2* tk_cand;             // [HWp][kTopkCap] pass 2: (exponent bits, reference row id = n*HWp + p)
+    int no_skew;                // dense kernel: 1 = both waves of a SIMD keep their barrier at the step end (VOSPROP_DENSE_SKEW=0, A/B only)
     unsigned long long* dbg;    // diagnostic builds only (-DVOSPROP_STAMP): per-wave cycle sums; else nullptr
 };
 

@@ -228,7 +228,7 @@ int build_segments(int TT, int NT, bool streamk, std::vector<std::vector<Segment
             // several short segments; a segment start (target fragments, staging prologue, partial write) costs about as
             // much as `seg_cost` tile steps, so U is chosen to equalise  U + c  and  tail share + c * segments
             static const char* sc_env = getenv("VOSPROP_SEGCOST");
-            const double seg_cost = sc_env ? atof(sc_env) : 3.0;
+            const double seg_cost = sc_env ? atof(sc_env) : 9.0;   // measured (r02 wall-clock stamps): ~6 us + the extras' lost lockstep
             int U = RX;
             double best = 1e30;
             for (int u = 1; u <= RX; ++u) {
@@ -344,9 +344,12 @@ int push_features(vosprop_ctx* ctx, const void* src, int dtype, Ring& r, int slo
 
 // e0 / e1 (optional): HIP events attached to the dispatch itself (hipExtLaunchKernelGGL) - they carry the kernel's own start and
 // end timestamps, like a profiler's, without the queue latency a pair of hipEventRecord calls around the launch would include
-void launch_prop_mode(const LastProp& lp, const PropArgs& a, int mode, hipStream_t s, hipEvent_t e0 = nullptr,
+void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStream_t s, hipEvent_t e0 = nullptr,
                       hipEvent_t e1 = nullptr) {
     const dim3 grid(lp.grid), block(kWaves * 64);
+    static const bool no_skew = getenv("VOSPROP_DENSE_SKEW") && atoi(getenv("VOSPROP_DENSE_SKEW")) == 0;
+    PropArgs a = a_in;
+    a.no_skew = no_skew ? 1 : 0;
     if (mode == 1) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 1>), grid, block, 0, s, a); return; }
     if (mode == 2) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 2>), grid, block, 0, s, a); return; }
     if (a.feat_f32) {   // VOSPROP_PREC_F32: the parity kernel (prop_f32.h)

@@ -29,7 +29,7 @@
 #include "common.h"
 
 #ifdef VOSPROP_STAMP
-#define VOSPROP_NSTAMP 12
+#define VOSPROP_NSTAMP 16
 // diagnostic build: STAMP_AT(k) adds the cycles since the previous stamp to bucket k (wave-uniform scalars)
 #define STAMP_DECL unsigned long long tsum[VOSPROP_NSTAMP] = {}; unsigned long long tprev = 0
 #define STAMP_ARGS , unsigned long long (&tsum)[VOSPROP_NSTAMP], unsigned long long& tprev

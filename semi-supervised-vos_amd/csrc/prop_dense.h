@@ -29,7 +29,8 @@
 
 namespace vosprop {
 
-constexpr int kRing5 = 5;   // LDS ring slots of the dense kernel (112 640 B + 20 KiB of per-lane constants <= 160 KiB)
+constexpr int kRing5 = 6;   // LDS ring slots of the dense kernel (135 168 B + 20 KiB of per-lane constants = 155 648 B <= 160 KiB)
+constexpr int kRingLast = (kRing5 - 1) * kLdsBuf;
 
 // rows 0..15 of one tile's softmax against the running max (mc = m c), sequential form (rescale path and the segment's last tile)
 template <bool PROB>
@@ -135,47 +136,64 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
     const unsigned char* const feat_base = (const unsigned char*)A.feat_ring;
 
     const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
+#ifdef VOSPROP_STAMP
+    unsigned long long t_seg = 0, rt0 = 0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");   // 100 MHz wall clock: launch ramp / tail
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_seg)::"memory");
+#endif
     for (int si = seg0; si < seg1; ++si) {
         const Segment sg = A.segs[si];
         const int tt = __builtin_amdgcn_readfirstlane(sg.tt);
         const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);
         const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
         const int part_slot = __builtin_amdgcn_readfirstlane(sg.slot);
+        STAMP_DECL;
+#ifdef VOSPROP_STAMP
+        tprev = t_seg;
+        STAMP_AT(12);   // 12: the segment record (and the previous segment's partial stores being issued)
+#endif
 
+        // What a segment start computes from the thread id is computed HERE, from an opaque copy: as loop invariants hoisted above
+        // the segment loop these values were spilled around the tile loop (256 registers) and every reload brought an
+        // `s_waitcnt vmcnt(0)` into the prologue, in front of the staging
+        int tid_l = tid, wd_l = A.Wd;
+        asm volatile("" : "+v"(tid_l), "+s"(wd_l));
+        const int j_l = tid_l & 31, h_l = (tid_l >> 5) & 1;
         // target (B operand) fragments: 32 columns x 256 channels per wave, resident in registers
-        const int t = tt * kBT + wave * kColsPerWave + j;
+        const int t = tt * kBT + wave * kColsPerWave + j_l;
         const int t_ld = t < A.HWp ? t : A.HWp - 1;
-        const bf16_t* trow = A.feat_ring + ((size_t)A.target_slot * A.HWp + t_ld) * kC + h * 8;
+        const bf16_t* trow = A.feat_ring + ((size_t)A.target_slot * A.HWp + t_ld) * kC + h_l * 8;
         bf16x8 Bt[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) Bt[ks] = *(const bf16x8*)(trow + ks * 16);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(Bt[ks]));   // hipcc's waits for these loads stay out of the tile loop
 
         // target-side spatial channels for both sigmas and the per-column constants g Q_t c -> LDS (own lane writes, own lane reads)
         if (!PROB) {
             const int tq = t < A.HW ? t : A.HW - 1;
-            const double at = (double)(tq / A.Wd), bt = (double)(tq % A.Wd);
+            const int trow_i = tq / wd_l;
+            const double at = (double)trow_i, bt = (double)(tq - trow_i * wd_l);
             const double tw = A.two_over_w, gm = A.gamma;
             const double qt = at * at + tw * at * bt + gm * bt * bt;
 #pragma unroll
             for (int sgm = 0; sgm < 2; ++sgm) {
-                const double g = sgm ? A.g2 : A.g1;
+                int sg_o = sgm;
+                asm volatile("" : "+s"(sg_o));      // (the splits of -g are per-segment work too, not spilled loop invariants)
+                const double g = sg_o ? A.g2 : A.g1;
                 float ah, am, al, bh, bm, bl, kh, km, kl;
                 split3((float)(g * (2.0 * at + tw * bt)), ah, am, al);
                 split3((float)(g * (2.0 * gm * bt + tw * at)), bh, bm, bl);
                 split3((float)(-g), kh, km, kl);
                 bf16x8 B;   // pairs with the reference-side table of engine.hip build_coord_table (prop_bf16.h has the derivation)
-                B[0] = (bf16_t)(h ? kl : ah);
-                B[1] = (bf16_t)(h ? kh : am);
-                B[2] = (bf16_t)(h ? km : al);
-                B[3] = (bf16_t)(h ? kh : bh);
-                B[4] = (bf16_t)(h ? 0.0f : bm);
-                B[5] = (bf16_t)(h ? 0.0f : bl);
-                B[6] = (bf16_t)(h ? 0.0f : kh);
-                B[7] = (bf16_t)(h ? 0.0f : km);
-                s_bx[sgm][tid] = B;
-                s_kq[sgm][tid] = (float)(g * qt * (double)c);
+                B[0] = (bf16_t)(h_l ? kl : ah);
+                B[1] = (bf16_t)(h_l ? kh : am);
+                B[2] = (bf16_t)(h_l ? km : al);
+                B[3] = (bf16_t)(h_l ? kh : bh);
+                B[4] = (bf16_t)(h_l ? 0.0f : bm);
+                B[5] = (bf16_t)(h_l ? 0.0f : bl);
+                B[6] = (bf16_t)(h_l ? 0.0f : kh);
+                B[7] = (bf16_t)(h_l ? 0.0f : km);
+                s_bx[sgm][tid_l] = B;
+                s_kq[sgm][tid_l] = (float)(g * qt * (double)c);
             }
         }
 
@@ -227,7 +245,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         };
         // "tile -1" (the first step's previous tile) has probabilities 0 and takes its labels from slot 4: zero them, or stale LDS
         // bits that happen to spell a NaN would turn 0 x NaN into the accumulators
-        if (tid < 2 * kLdsLab / 16) *(f32x4*)(smem + 4 * kLdsBuf + kOffLabHi + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        float zf = 0.0f;
+        asm volatile("" : "+v"(zf));
+        if (tid_l < 2 * kLdsLab / 16) *(f32x4*)(smem + kRingLast + kOffLabHi + tid_l * 16) = f32x4{zf, zf, zf, zf};
         stage_seek(0);
         for (int q = 0; q < 3; ++q) {   // prologue: tiles 0, 1, 2
             stage_bases();
@@ -236,12 +256,24 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             stage_piece(smem_base + q * kLdsBuf, 2);
             stage_advance();
         }
+        // the target fragments are "used" HERE: their loads (issued first) fly under the prior-constant arithmetic and the staging of
+        // the first three tiles, one memory latency per segment start instead of two - and hipcc's waits for them stay out of the
+        // tile loop
+#ifdef VOSPROP_STAMP
+        STAMP_AT(13);   // 13: issue of the target-fragment loads, prior constants, staging of the first three tiles
+#endif
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(Bt[ks]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef VOSPROP_STAMP
+        STAMP_AT(14);   // 14: wait for all of it
+#endif
         __syncthreads();
 
-        STAMP_DECL;
 #ifdef VOSPROP_STAMP
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+        tsum[7] += tprev - t_seg;   // 7: segment prologue (target fragments, prior constants, first three tiles)
+        tsum[10] += 1;              // 10: segments
 #endif
         // compute cursor (pixel tile, frame) of the tile whose SCORES are being computed
         int ctile = r_lo / N, cn = r_lo - ctile * N;
@@ -257,12 +289,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         for (int r = 0; r < 16; ++r) S1[r] = -__builtin_inff();   // "tile -1": every probability 0 (whatever labels slot 4 holds)
         // ring slots of tile p (cur), p+1 (nxt), p-1 (prv), p+3 (stg): counters modulo 5
         // (kept as byte offsets into the ring)
-        int s_cur = 0, s_nxt = kLdsBuf, s_prv = 4 * kLdsBuf, s_stg = 3 * kLdsBuf;
+        int s_cur = 0, s_nxt = kLdsBuf, s_prv = kRingLast, s_stg = 3 * kLdsBuf;
         auto ring_advance = [&]() __attribute__((always_inline)) {
             s_prv = s_cur;
             s_cur = s_nxt;
-            s_nxt = s_nxt == 4 * kLdsBuf ? 0 : s_nxt + kLdsBuf;
-            s_stg = s_stg == 4 * kLdsBuf ? 0 : s_stg + kLdsBuf;
+            s_nxt = s_nxt == kRingLast ? 0 : s_nxt + kLdsBuf;
+            s_stg = s_stg == kRingLast ? 0 : s_stg + kLdsBuf;
         };
 
         // finish tile p-1: rescale check (rare), denominators, label MFMAs
@@ -287,7 +319,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         };
 
         // one step: scores of tile p into S, softmax of tile p-1 (scores Sp, labels labp) in the gaps of the chain
-        auto step = [&](f32x16& S, const f32x16& Sp) __attribute__((always_inline)) {
+        auto step = [&](auto grp, f32x16& S, const f32x16& Sp) __attribute__((always_inline)) {
+            constexpr bool MID_BARRIER = decltype(grp)::value;   // second wave of every SIMD: its barrier sits after gap 7
             const unsigned char* lb = smem + s_cur;
             const unsigned char* lbn = smem + s_nxt;
             const unsigned b_st = smem_base + (unsigned)s_stg;
@@ -358,6 +391,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                     } else {
                         qprev = aq;
                     }
+                }
+                if (MID_BARRIER && ks == 7) {
+                    // this wave's pieces of tile p+2 (issued in step p-1) have landed: only the two of this step may be in flight
+                    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
                 }
 #ifndef VOSPROP_DENSE_NO_SGB
                 // pin the interleave (cdna guide T19): after each score MFMA its fragment refill and the 4-5 VALU instructions
@@ -430,13 +467,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #ifdef VOSPROP_STAMP
                 STAMP_AT(4);   // 4: tail mask, prior tile, cursor
 #endif
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                if (!MID_BARRIER) {
+                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 #ifdef VOSPROP_STAMP
-                STAMP_AT(5);   // 5: wait for the own pieces of tile p+2
+                    STAMP_AT(5);   // 5: wait for the own pieces of tile p+2
 #endif
 #if !(VOSPROP_DABLATE & 8)
-                __syncthreads();
+                    __syncthreads();
 #endif
+                }
 #ifdef VOSPROP_STAMP
                 STAMP_AT(6);   // 6: barrier
 #endif
@@ -444,10 +483,30 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             ring_advance();
         };
 
+        // ---- ONE barrier per step and wave, at a different place for the two waves of a SIMD (VOSPROP_DENSE_SKEW, default on):
+        // waves 0-3 at the end of their step p, waves 4-7 after gap 7 of THEIR step p - so the second wave of every SIMD runs half
+        // a step behind the first, and its serial tail (rescale check, label MFMAs, prior tile, cursor) sits under its partner's
+        // chain instead of under its partner's barrier wait (stamps, profiles/r02_dense_kernel_skew.txt).  With t in local steps:
+        // tile t is written at t-3+[.1,.8], read at [t-.5, t+1.6]; barrier k is passed at local time k+1 (first group) / k+.5
+        // (second).  Visibility: every wave has waited for its pieces of tile k+2 before barrier k; the earliest read of tile t
+        // (local t-.5) is after barrier t-2 (first group) or t-1 (second).  Re-use: the slot of tile t is re-targeted for tile t+6
+        // at local t+3.1 or later, i.e. after barrier t+2, which every wave passes at local >= t+2.5 > t+1.6 (with FIVE slots the
+        // first group's pieces would overtake the second group's label reads - hence six).
+        constexpr bool kSkew = MAT == 0;
+        const bool grp_b = kSkew && wave >= kWaves / 2 && !A.no_skew;
+        typedef std::integral_constant<bool, false> GrpA;
+        typedef std::integral_constant<bool, true> GrpB;
         int p = 0;
-        for (; p + 1 < n_steps; p += 2) {
-            step(S0, S1);
-            step(S1, S0);
+        if (grp_b) {
+            for (; p + 1 < n_steps; p += 2) {
+                step(GrpB(), S0, S1);
+                step(GrpB(), S1, S0);
+            }
+        } else {
+            for (; p + 1 < n_steps; p += 2) {
+                step(GrpA(), S0, S1);
+                step(GrpA(), S1, S0);
+            }
         }
         // the segment's last tile has no chain to hide under (its labels sit in slot s_prv after the last ring_advance)
         auto drain = [&](const f32x16& Sp) __attribute__((always_inline)) {
@@ -459,7 +518,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
         };
         if (p < n_steps) {
-            step(S0, S1);
+            if (grp_b) step(GrpB(), S0, S1);
+            else step(GrpA(), S0, S1);
             if (MAT != 1) drain(S0);
         } else {
             if (MAT != 1) drain(S1);
@@ -467,6 +527,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the look-ahead pieces before the ring is re-staged
         __syncthreads();
 #ifdef VOSPROP_STAMP
+        STAMP_AT(8);                // 8: last tile's softmax + the segment's closing barrier
+        t_seg = tprev;              // the partial's stores count towards the next segment's prologue
         if (A.dbg && lane == 0)
             for (int k = 0; k < VOSPROP_NSTAMP; ++k)
                 atomicAdd(&A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + k], tsum[k]);
@@ -474,8 +536,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 
         if (MAT == 1) continue;
         // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
-        float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + j;
-        int hh = h;
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));
+        float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + (tid_e & 31);
+        int hh = (tid_e >> 5) & 1;
         asm volatile("" : "+v"(part), "+v"(hh));   // row addresses are computed HERE: hoisted out of the segment loop as loop
                                                     // invariants they were 22 registers spilled to scratch at kernel entry
         const float lsum = half_sum(st.l);
@@ -489,6 +553,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
         }
     }
+#ifdef VOSPROP_STAMP
+    if (A.dbg && lane == 0) {
+        unsigned long long rt1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+        A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + 9] = rt0;
+        A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + 11] = rt1;
+    }
+#endif
 }
 
 }  // namespace vosprop
