@@ -150,11 +150,17 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
                                                       const int* __restrict__ plist, int d, int HW, float c,
                                                       float* __restrict__ pred, uint8_t* __restrict__ cls,
                                                       bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, int prob,
-                                                      const UpArgs up) {
+                                                      const UpArgs up, const uint4* __restrict__ cp_src,
+                                                      uint4* __restrict__ cp_dst, int cp_n) {
     __shared__ float red[4][kMaxClasses + 2][64];
     __shared__ float outv[kMaxClasses][64];
     __shared__ uint8_t clsv[64];
     const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
+    // Optional rider: the ring copy of the frame just propagated (cp_n 16-byte units of channels-last bf16 features, caller's buffer
+    // -> ring slot; vosprop_step).  The propagation kernel read the target from the caller's buffer; the slot is first needed as a
+    // REFERENCE by the next step.  This kernel is latency-bound (three dependent round trips), eight independent 16-byte copies per
+    // thread in front of them cost nothing and save the separate copy launch and its dispatch gap.
+    for (int i = blockIdx.x * 256 + tid; i < cp_n; i += gridDim.x * 256) cp_dst[i] = cp_src[i];
     const int t = blockIdx.x * 64 + col;
     const int tt = (blockIdx.x * 64) / kBT, tcol = (blockIdx.x * 64) % kBT + col;
     const size_t ustride = (size_t)(2 + d) * kBT;

@@ -79,6 +79,8 @@ struct PropArgs {
     const Segment* segs;        // segment table of this launch
     const int* seg_off;         // [grid + 1] segments of workgroup b: segs[seg_off[b]] .. segs[seg_off[b + 1] - 1]
     int target_slot;
+    const bf16_t* target_feat;  // dense bf16 kernel: the target frame's features [target_rows][kC] - its ring slot, or the caller's own
+    int target_rows;            // channels-last bf16 buffer (HW rows) when the ring copy rides in combine_kernel (engine.hip vosprop_step)
     int n_ref;
     int HW, HWp, Wd;
     int d;

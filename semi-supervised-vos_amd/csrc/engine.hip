@@ -95,6 +95,8 @@ struct vosprop_ctx {
     int up_H = 0, up_W = 0;
     float up_sy = 0.f, up_sx = 0.f;
     uint8_t* fuse_mask = nullptr;  // set by vosprop_step around propagate(): the mask combine_kernel should write
+    const void* fuse_push = nullptr;   // set by vosprop_step around propagate(): channels-last bf16 features of the target frame that
+                                       // the propagation reads in place and combine_kernel copies into the target's ring slot
     LastProp last;
     std::vector<Plan> plans;   // cache keyed by NT (n_ref * tiles)
     vosprop_stats stats;
@@ -435,6 +437,9 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     if (!prob && frame_idx > 15)   // reference src/model/predict.py:59-64
         for (int n = 0; n < n_ref - kContinuousFrame; ++n) a.sparse_mask |= 1ull << n;
     a.target_slot = target_slot;
+    bf16_t* const target_in_ring = ring.feat ? ring.feat + (size_t)target_slot * ctx->HWp * kC : nullptr;
+    a.target_feat = ctx->fuse_push ? (const bf16_t*)ctx->fuse_push : target_in_ring;
+    a.target_rows = ctx->fuse_push ? ctx->HW : ctx->HWp;
     a.n_ref = n_ref;
     a.HW = ctx->HW;
     a.HWp = ctx->HWp;
@@ -514,8 +519,13 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
             up.H = ctx->H; up.W = ctx->W; up.Hd = ctx->cfg.feat_h; up.Wd = ctx->cfg.feat_w;
             up.sx = ctx->up_sx;
         }
+        const int cp_n = ctx->fuse_push ? (int)((size_t)ctx->HW * kC * sizeof(bf16_t) / 16) : 0;
         hipLaunchKernelGGL(combine_kernel, cgrid, dim3(256), 0, s, ctx->part, plan->d_off, plan->d_list, d, ctx->HW, a.c, pred,
-                           cls, new_lab_hi, new_lab_lo, prob ? 1 : 0, up);
+                           cls, new_lab_hi, new_lab_lo, prob ? 1 : 0, up, (const uint4*)ctx->fuse_push, (uint4*)target_in_ring, cp_n);
+        // re-runs of this propagation (vosprop_time_last_propagation, debug hooks) read the target from the ring: the caller's
+        // buffer is only promised until the work enqueued by this call has run
+        a.target_feat = target_in_ring;
+        a.target_rows = ctx->HWp;
     }
     HIP_TRY(ctx, hipGetLastError());
 #ifdef VOSPROP_STAMP
@@ -904,7 +914,13 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     const int f = ctx->frame_idx;
     const int slot = f % R.cap;
     const size_t lab_slot = (size_t)ctx->tiles * 2 * 64 * 8;
-    int rc = push_features(ctx, feat_dev, feat_dtype, R, slot, s);
+    // Channels-last bf16 features on the dense bf16 path are not copied into the ring up front: the propagation kernel reads the
+    // target frame where the encoder left it and combine_kernel carries the copy (one launch and one dispatch gap fewer per frame)
+    static const bool no_fuse_push = getenv("VOSPROP_FUSE_PUSH") && atoi(getenv("VOSPROP_FUSE_PUSH")) == 0;
+    static const bool two_burst_env = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
+    const bool fuse_push = f > 0 && feat_dtype == (VOSPROP_DT_BF16 | VOSPROP_LAYOUT_HWC) && ctx->cfg.precision == VOSPROP_PREC_BF16 &&
+                           ctx->cfg.topk == 0 && !ctx->cfg.materialise && !no_fuse_push && !two_burst_env;
+    int rc = fuse_push ? VOSPROP_OK : push_features(ctx, feat_dev, feat_dtype, R, slot, s);
     if (rc) return rc;
     if (f == 0) {   // reference inference_utils.py:33-48: frame 0 only seeds the history
         ctx->frame_idx = 1;
@@ -920,9 +936,11 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     // combine_kernel also writes the new label of this frame (reference inference_utils.py:67-71) into its ring slot
     const bool fuse_up = mask_out_dev && ctx->cfg.topk == 0;      // dense path: combine_kernel writes the mask itself
     ctx->fuse_mask = fuse_up ? mask_out_dev : nullptr;
+    ctx->fuse_push = fuse_push ? feat_dev : nullptr;
     rc = propagate(ctx, R, slots, n_ref, f, slot, ctx->d, prob, prob, ctx->cfg.sigma1, ctx->cfg.sigma2,
                    ctx->cfg.temperature, ctx->pred_buf, cls_slot, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s);
     ctx->fuse_mask = nullptr;
+    ctx->fuse_push = nullptr;
     if (rc) return rc;
     if (pred_out_dev)
         HIP_TRY(ctx, hipMemcpyAsync(pred_out_dev, ctx->pred_buf, (size_t)ctx->d * ctx->HW * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -161,8 +161,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         const int j_l = tid_l & 31, h_l = (tid_l >> 5) & 1;
         // target (B operand) fragments: 32 columns x 256 channels per wave, resident in registers
         const int t = tt * kBT + wave * kColsPerWave + j_l;
-        const int t_ld = t < A.HWp ? t : A.HWp - 1;
-        const bf16_t* trow = A.feat_ring + ((size_t)A.target_slot * A.HWp + t_ld) * kC + h_l * 8;
+        const int t_ld = t < A.target_rows ? t : A.target_rows - 1;
+        const bf16_t* trow = A.target_feat + (size_t)t_ld * kC + h_l * 8;
         bf16x8 Bt[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) Bt[ks] = *(const bf16x8*)(trow + ks * 16);
