@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
                                                       float* __restrict__ pred, uint8_t* __restrict__ cls,
                                                       bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, int prob,
                                                       const UpArgs up, const uint4* __restrict__ cp_src,
-                                                      uint4* __restrict__ cp_dst, int cp_n) {
+                                                      uint4* __restrict__ cp_dst, int cp_n, int no_l) {
     __shared__ float red[4][kMaxClasses + 2][64];
     __shared__ float outv[kMaxClasses][64];
     __shared__ uint8_t clsv[64];
@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
             sc[q] = __builtin_amdgcn_exp2f((red[q][0][col] - Mt) * c);
             Lt += red[q][1][col] * sc[q];
         }
-        const float inv = 1.0f / Lt;
+        // no_l: the propagation kernel ran without denominators (label mode, nobody asked for the prediction): `pred` then holds
+        // the un-normalised numerators, whose arg-max is the same
+        const float inv = no_l ? 1.0f : 1.0f / Lt;
         int best = 0;
         float bv = -1.0f;
         for (int k = 0; k < d; ++k) {

@@ -40,6 +40,7 @@ struct LastProp {
     int grid = 0;
     bool prob = false, lab_lo = false;
     bool materialise = false;
+    bool no_l = false;    // dense label mode, prediction not requested: prop_dense_kernel<..., NEED_L = false>
     int topk = 0;
     int rows_pass1 = 0;
     const int* d_off = nullptr;    // plan lists (top-k select between the passes)
@@ -95,6 +96,7 @@ struct vosprop_ctx {
     int up_H = 0, up_W = 0;
     float up_sy = 0.f, up_sx = 0.f;
     uint8_t* fuse_mask = nullptr;  // set by vosprop_step around propagate(): the mask combine_kernel should write
+    bool mask_only = false;            // set by vosprop_step around propagate(): the caller did not ask for the prediction
     const void* fuse_push = nullptr;   // set by vosprop_step around propagate(): channels-last bf16 features of the target frame that
                                        // the propagation reads in place and combine_kernel copies into the target's ring slot
     LastProp last;
@@ -384,7 +386,10 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
             else hipLaunchKernelGGL((prop_dense_kernel<true, false>), grid, block, 0, s, a);
         } else {
             if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<false, true>), grid, block, 0, s, a);
-            else if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, e0, e1, 0, a);
+            else if (lp.no_l) {
+                if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false, 0, false>), grid, block, 0, s, e0, e1, 0, a);
+                else hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false>), grid, block, 0, s, a);
+            } else if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, e0, e1, 0, a);
             else hipLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, a);
         }
         return;
@@ -469,6 +474,9 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.part = ctx->part;
     a.part_rows = topk ? 2 : 2 + d;
     lp.materialise = ctx->cfg.materialise != 0;
+    static const bool keep_l = getenv("VOSPROP_KEEP_L") != nullptr;           // A/B: always accumulate the denominators
+    static const bool two_burst_l = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
+    lp.no_l = ctx->mask_only && !prob && !lab_lo && !topk && !f32 && !lp.materialise && !keep_l && !two_burst_l;
     if (lp.materialise) {
         if (f32 || topk) return fail(ctx, VOSPROP_E_UNSUPPORTED, "the materialised-affinity variant is dense, bf16 path only");
         const size_t need = (size_t)n_ref * ctx->tiles * ((size_t)ctx->TT * kWaves) * 64 * 16 * sizeof(bf16_t);
@@ -486,7 +494,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.tk_m = ctx->tk_m;
     a.tk_cnt = ctx->tk_cnt;
     a.tk_cand = ctx->tk_cand;
-    const bool timed = ctx->timing && !f32 && !topk && !prob && !lab_lo && !lp.materialise && ctx->tev_used + 2 <= 2 * 4096;
+    const bool timed = ctx->timing && !f32 && !topk && !prob && !lab_lo && !lp.materialise && ctx->tev_used + 2 <= 2 * 4096;   // (either NEED_L form)
     if (timed) {
         while (ctx->tev.size() < ctx->tev_used + 2) {
             hipEvent_t e;
@@ -521,7 +529,8 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         }
         const int cp_n = ctx->fuse_push ? (int)((size_t)ctx->HW * kC * sizeof(bf16_t) / 16) : 0;
         hipLaunchKernelGGL(combine_kernel, cgrid, dim3(256), 0, s, ctx->part, plan->d_off, plan->d_list, d, ctx->HW, a.c, pred,
-                           cls, new_lab_hi, new_lab_lo, prob ? 1 : 0, up, (const uint4*)ctx->fuse_push, (uint4*)target_in_ring, cp_n);
+                           cls, new_lab_hi, new_lab_lo, prob ? 1 : 0, up, (const uint4*)ctx->fuse_push, (uint4*)target_in_ring, cp_n,
+                           lp.no_l ? 1 : 0);
         // re-runs of this propagation (vosprop_time_last_propagation, debug hooks) read the target from the ring: the caller's
         // buffer is only promised until the work enqueued by this call has run
         a.target_feat = target_in_ring;
@@ -937,10 +946,12 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     const bool fuse_up = mask_out_dev && ctx->cfg.topk == 0;      // dense path: combine_kernel writes the mask itself
     ctx->fuse_mask = fuse_up ? mask_out_dev : nullptr;
     ctx->fuse_push = fuse_push ? feat_dev : nullptr;
+    ctx->mask_only = pred_out_dev == nullptr;
     rc = propagate(ctx, R, slots, n_ref, f, slot, ctx->d, prob, prob, ctx->cfg.sigma1, ctx->cfg.sigma2,
                    ctx->cfg.temperature, ctx->pred_buf, cls_slot, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s);
     ctx->fuse_mask = nullptr;
     ctx->fuse_push = nullptr;
+    ctx->mask_only = false;
     if (rc) return rc;
     if (pred_out_dev)
         HIP_TRY(ctx, hipMemcpyAsync(pred_out_dev, ctx->pred_buf, (size_t)ctx->d * ctx->HW * sizeof(float), hipMemcpyDeviceToDevice, s));

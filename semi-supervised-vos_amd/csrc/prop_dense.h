@@ -31,6 +31,7 @@ namespace vosprop {
 
 constexpr int kRing5 = 6;   // LDS ring slots of the dense kernel (135 168 B + 20 KiB of per-lane constants = 155 648 B <= 160 KiB)
 constexpr int kRingLast = (kRing5 - 1) * kLdsBuf;
+constexpr float kAlarmExp = 8.0f;   // log2(kSumThrV3)
 
 // rows 0..15 of one tile's softmax against the running max (mc = m c), sequential form (rescale path and the segment's last tile)
 template <bool PROB>
@@ -64,8 +65,13 @@ __device__ __forceinline__ void softmax_rows(const f32x16& Sp, const float (&Wt)
 // and reads it back): MAT 1 runs only the score MFMAs and stores every 32 x 32 score tile to HBM as bf16 (64 lanes x 32 B,
 // accumulator order), MAT 2 runs everything EXCEPT the score MFMAs and takes the score tiles back from HBM (two LDS-DMA pieces per
 // wave and step in place of the two feature pieces).  2 x N HW^2 x 2 B of traffic per step: 7.46 GB at 720p.
-template <bool PROB, bool LAB_LO, int MAT = 0>
+// NEED_L = false (label propagation with only the class map / mask wanted): the softmax denominators are not accumulated.  They
+// scale every class of a column alike, so the arg-max - all that vosprop_step's mask and new label depend on - does not see them;
+// the per-tile sums that also served as the overflow alarm of the optimistic softmax become a running max (v_max3: 8 instructions
+// per tile instead of 16 adds).  The partial's l row is written as 0 and combine_kernel does not divide (engine.hip propagate).
+template <bool PROB, bool LAB_LO, int MAT = 0, bool NEED_L = true>
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropArgs A) {
+    static_assert(NEED_L || (!PROB && !LAB_LO && MAT == 0), "denominators may only be dropped in plain label mode");
     __shared__ __attribute__((aligned(16))) unsigned char smem[kRing5 * kLdsBuf];
     __shared__ __attribute__((aligned(16))) bf16x8 s_bx[2][kWaves * 64];   // per-lane prior constants (see prop_bf16.h)
     __shared__ float s_kq[2][kWaves * 64];
@@ -299,7 +305,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 
         // finish tile p-1: rescale check (rare), denominators, label MFMAs
         auto finish_prev = [&](const f32x16& Sp, const LabFrag<LAB_LO>& labp, float lt0, float lt1, bf16x8& pk0, bf16x8& pk1) __attribute__((always_inline)) {
-            if (__any(lt0 + lt1 > kSumThrV3)) {
+            // alarm: a term of this tile above 2^8 (NEED_L: the tile's partial denominator above 2^8)
+            if (__any(NEED_L ? lt0 + lt1 > kSumThrV3 : lt0 > st.m + kAlarmExp / c)) {
                 // raise the running max (shared by the two half-waves of a column), rescale what was accumulated against the old
                 // one exactly once, redo this tile against the new one (cdna guide T13 hazard; Y does not hold this tile yet)
                 asm volatile("; rescale" ::: "memory");
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 st.m = mn;
                 softmax_rows<PROB>(Sp, Wt, c, mn * c, lt0, lt1, pk0, pk1);
             }
-            st.l += lt0 + lt1;
+            if (NEED_L) st.l += lt0 + lt1;
             label_mfmas<LAB_LO>(labp, pk0, pk1, st.Y);
         };
 
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             stage_bases();
             LabFrag<LAB_LO> labp;
             const float mc = st.m * c;
-            float lt0 = 0.0f, lt1 = 0.0f, qprev = 0.0f;
+            float lt0 = NEED_L ? 0.0f : kNegBig, lt1 = 0.0f, qprev = 0.0f;
             bf16x8 pk0, pk1;
             const unsigned char* arow = lb + j * kRowB + h * 16;
             const unsigned char* nrow = lbn + j * kRowB + h * 16;
@@ -382,8 +389,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                         qprev = q;
                     }
                 } else {
-                    if (ks & 1) lt1 += q;
-                    else lt0 += q;
+                    if (NEED_L) {
+                        if (ks & 1) lt1 += q;
+                        else lt0 += q;
+                    } else if (ks & 1) {      // overflow alarm only, from the raw scores (off the exponential's dependency chain):
+                        lt0 = __builtin_fmaxf(__builtin_fmaxf(lt0, Sp[ks - 1]), Sp[ks]);   // lt0 = max of the tile's scores
+                    }
                     const float aq = q * Wt[ks];
                     if (ks & 1) {
                         if (ks < 8) { pk0[ks - 1] = (bf16_t)qprev; pk0[ks] = (bf16_t)aq; }
@@ -515,6 +526,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             LabFrag<LAB_LO> labp;
             labp.load(smem + s_prv, lane);
             softmax_rows<PROB>(Sp, Wt, c, st.m * c, lt0, lt1, pk0, pk1);
+            if (!NEED_L) {      // the alarm of this form looks at the scores
+                float sv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[r] = Sp[r];
+                lt0 = max16v(sv);
+                lt1 = 0.0f;
+            }
             finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
         };
         if (p < n_steps) {

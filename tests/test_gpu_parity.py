@@ -322,3 +322,39 @@ def test_mask_is_the_nearest_upsampling_of_the_class_map(vos, dev, H, W, topk):
         assert mask.shape == (H, W)
         assert torch.equal(mask.cpu(), want), float((mask.cpu() != want).float().mean())
     eng.close()
+
+
+@pytest.mark.parametrize('layout', ['nchw_f32', 'hwc_bf16'])
+def test_mask_only_steps_equal_steps_that_return_the_prediction(vos, dev, layout):
+    """A step that is not asked for the prediction runs the propagation kernel WITHOUT softmax denominators (they scale every
+    class of a column alike; prop_dense.h NEED_L = false), and with channels-last bf16 features it reads the target frame in
+    place while combine_kernel carries the ring copy.  A 24-frame roll-out (past frame 15: both sigmas; 9 references) must give
+    the same masks as the roll-out that returns predictions, frame by frame, and peaky scores must still trip the rescale path."""
+    H, W = 120, 214
+    Hd, Wd = vos.feature_map_size(H, W)
+    rs = np.random.RandomState(77)
+    ann = np.zeros((H, W), np.uint8)
+    ann[20:70, 30:120] = 1
+    ann[60:110, 100:200] = 2
+    feats = []
+    for t in range(24):
+        f = torch.from_numpy(rs.randn(256, Hd, Wd).astype(np.float32) * (0.25 if t % 5 else 1.5)).to(dev)
+        if layout == 'hwc_bf16':
+            f = f.to(torch.bfloat16)[None].contiguous(memory_format=torch.channels_last)[0]
+        feats.append(f)
+    masks = {}
+    for want_pred in (True, False):
+        eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=9)
+        eng.begin_video(ann)
+        out = []
+        for f in feats:
+            pred, mask = eng.step(f, want_pred=want_pred, want_mask=True)
+            assert (pred is not None) == (want_pred and mask is not None)
+            if mask is not None:
+                out.append(mask.cpu())
+        eng.close()
+        masks[want_pred] = out
+    assert len(masks[True]) == len(masks[False]) == 23
+    for a, b in zip(masks[True], masks[False]):
+        assert torch.equal(a, b), float((a != b).float().mean())
+    assert len({int(m.sum()) for m in masks[False]}) > 1

@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--topk', type=int, default=0)
     ap.add_argument('--materialise', action='store_true', help='the materialised-affinity (HBM-stress) variant')
     ap.add_argument('--f32', action='store_true', help='the f32 parity path (VOSPROP_PREC_F32)')
+    ap.add_argument('--want-pred', action='store_true', help='stateful: the timed step also returns the prediction (denominators kept)')
     ap.add_argument('--stateful', action='store_true', help='time the begin_video/step path (the dense one-hot kernel)')
     args = ap.parse_args()
     vos = importlib.import_module('semi-supervised-vos_amd')
@@ -45,8 +46,10 @@ def main():
         ann[: Hd * 4, : Wd * 4] = args.d - 1
         ann[Hd * 4:, Wd * 2: Wd * 6] = 1
         eng.begin_video(ann)
-        for t in range(T):
-            out, _ = eng.step(feats[t])
+        for t in range(T):      # the last step is the one that is re-timed: like the frame loop, it only asks for the mask
+            last = t == T - 1 and not args.want_pred
+            o, m = eng.step(feats[t], want_pred=not last, want_mask=True)
+            out = o if o is not None else (m.float() if m is not None else None)
     else:
         out = eng.predict(feats[:fi], feats[fi], oh[:, :fi], fi, 40, args.ref_num, 1.0, 8.0, 21.0, args.prob)
     torch.cuda.synchronize()
