@@ -90,6 +90,7 @@ struct PropArgs {
     double two_over_w, gamma;   // 2/W_d, 1 + 1/W_d^2
     int part_rows;              // rows of one partial slot: 2 + d (dense), 1 + 2*kTopkMax (top-k pass 1), 2 (top-k pass 2)
     // top-k variant (two passes, see prop_bf16.h)
+    int tk_k;                   // k of the top-k variant (pass 1 maintains ceil(k / 8) * 8 list slots)
     const float* tk_thr;        // [HWp] pass 2: lower bound of the k-th largest weighted exponent of each target pixel
     const float* tk_m;          // [HWp] pass 2: column max of the raw scores (exact softmax max, from pass 1)
     unsigned* tk_cnt;           // [HWp] pass 2: number of candidates appended per target pixel

@@ -490,6 +490,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         }
         a.smat = ctx->smat;
     }
+    a.tk_k = topk;
     a.tk_thr = ctx->tk_thr;
     a.tk_m = ctx->tk_m;
     a.tk_cnt = ctx->tk_cnt;

@@ -352,8 +352,18 @@ __device__ __forceinline__ void mask_tail_rows(f32x16& S, int h, int rows_valid)
 }
 
 // LW = log2 of the prior tile (prior_tile<true>): the weighted exponent the top-k ranks by is E = S c + LW.
+// insert x into the first KS slots of the descending list: ONE v_med3 per slot, bottom up (new v[i] = med3(v[i-1], v[i], x): v[i]
+// if x is below it, x if it lands here, v[i-1] if it lands above), then v[0] = max(v[0], x)
+template <int KS>
+__device__ __forceinline__ void topk_insert(TopkList& lst, float x) {
+#pragma unroll
+    for (int i = KS - 1; i >= 1; --i) lst.v[i] = __builtin_amdgcn_fmed3f(lst.v[i - 1], lst.v[i], x);
+    lst.v[0] = vmaxf(lst.v[0], x);
+}
+
+// slots8 = ceil(k / 8): only the first 8 * slots8 list slots are maintained (the k-th largest group maximum needs k of them)
 __device__ __forceinline__ void tile_topk_pass1(f32x16& S, const float (&LW)[16], float& colmax, TopkList& lst, int h, float c,
-                                                bool tail, int rows_valid) {
+                                                bool tail, int rows_valid, int slots8) {
     if (tail) {
         asm volatile("; tail tile" ::: "memory");
         mask_tail_rows(S, h, rows_valid);
@@ -365,13 +375,11 @@ __device__ __forceinline__ void tile_topk_pass1(f32x16& S, const float (&LW)[16]
         Sr[r] = S[r];
     }
     colmax = vmaxf(colmax, max16v(Sr));
-    float x = max16v(E);
-#pragma unroll
-    for (int i = 0; i < kTopkMax; ++i) {   // insert x into the descending list (2 ops per slot, branch-free)
-        const float hi = vmaxf(lst.v[i], x);
-        x = vminf(lst.v[i], x);
-        lst.v[i] = hi;
-    }
+    const float x = max16v(E);
+    if (slots8 == 1) topk_insert<8>(lst, x);          // wave-uniform
+    else if (slots8 == 2) topk_insert<16>(lst, x);
+    else if (slots8 == 3) topk_insert<24>(lst, x);
+    else topk_insert<kTopkMax>(lst, x);
 }
 
 __device__ __forceinline__ void tile_topk_pass2(f32x16& S, const float (&LW)[16], float mc, float& lsum, int h, float c,
@@ -494,6 +502,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
         }
 
         TopkList lst;            // MODE 1 only
+        const int tk_slots8 = __builtin_amdgcn_readfirstlane((A.tk_k + 7) >> 3);
         float tk_thr = 3.0e38f;  // MODE 2 only
         if (MODE == 1) {
 #pragma unroll
@@ -659,7 +668,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
                 tile_softmax<PROB>(h, S, pa, st, c, tail, rows_last STAMP_PASS);
                 lab_prev = lab;
             } else if (MODE == 1) {
-                tile_topk_pass1(S, Wt, st.m, lst, h, c, tail, rows_last);
+                tile_topk_pass1(S, Wt, st.m, lst, h, c, tail, rows_last, tk_slots8);
             } else {
                 tile_topk_pass2(S, Wt, st.m * c, st.l, h, c, tk_thr, tail, rows_last,
                                 (unsigned)(cn * A.HWp + ctile * kTileR), t, A);

@@ -110,9 +110,11 @@ class PropagationEngine:
     def frame_index(self):
         return self._L.vosprop_frame_index(self._ctx)
 
-    def step(self, features, want_pred=True, want_mask=True):
+    def step(self, features, want_pred=True, want_mask=True, mask_out=None):
         """features: (C,H_d,W_d) or (1,C,H_d,W_d) tensor on this engine's GPU (f32 / f16 / bf16).
-        Frame 0 returns (None, None); later frames return (prediction (d,HW) f32 | None, mask (H,W) u8 | None)."""
+        Frame 0 returns (None, None); later frames return (prediction (d,HW) f32 | None, mask (H,W) u8 | None).
+        mask_out: optional contiguous (H,W) uint8 tensor on this GPU the mask is written into (e.g. a slice of a batch buffer
+        that goes back to the host in one copy) instead of a fresh tensor."""
         if self.frame_index < 0:
             raise VospropError('step() before begin_video()')
         f = features[0] if features.dim() == 4 else features
@@ -131,7 +133,12 @@ class PropagationEngine:
         if not first:
             if want_pred:
                 pred = torch.empty((self.d, self.HW), dtype=torch.float32, device=self.device)
-            if want_mask:
+            if mask_out is not None:
+                if (mask_out.dtype != torch.uint8 or tuple(mask_out.shape) != (self.H, self.W) or mask_out.device != self.device
+                        or not mask_out.is_contiguous()):
+                    raise ValueError(f'mask_out must be a contiguous ({self.H},{self.W}) uint8 tensor on {self.device}')
+                mask = mask_out
+            elif want_mask:
                 mask = torch.empty((self.H, self.W), dtype=torch.uint8, device=self.device)
         rc = self._L.vosprop_step(self._ctx, ctypes.c_void_p(f.data_ptr()), DT_CODES[f.dtype] | (LAYOUT_HWC if hwc else 0),
                                   ctypes.c_void_p(pred.data_ptr()) if pred is not None else None,

@@ -46,9 +46,8 @@ def main():
         ann[: Hd * 4, : Wd * 4] = args.d - 1
         ann[Hd * 4:, Wd * 2: Wd * 6] = 1
         eng.begin_video(ann)
-        for t in range(T):      # the last step is the one that is re-timed: like the frame loop, it only asks for the mask
-            last = t == T - 1 and not args.want_pred
-            o, m = eng.step(feats[t], want_pred=not last, want_mask=True)
+        for t in range(T):      # like the frame loop, the steps only ask for the mask (--want-pred: and the prediction)
+            o, m = eng.step(feats[t], want_pred=args.want_pred, want_mask=True)
             out = o if o is not None else (m.float() if m is not None else None)
     else:
         out = eng.predict(feats[:fi], feats[fi], oh[:, :fi], fi, 40, args.ref_num, 1.0, 8.0, 21.0, args.prob)
