@@ -119,8 +119,11 @@ int vosprop_begin_video_labels_on(vosprop_ctx* ctx, const uint8_t* cls_lowres_ho
  *              one-hot(argmax) or the prediction itself in probability mode (:67-70); history append
  *              (:71-72); nearest up-sample + argmax (:74-75).
  * feat_dev   (C, H_d, W_d) in NCHW order - or (H_d*W_d, C) with VOSPROP_LAYOUT_HWC - element type feat_dtype (the encoder output
- *            features[0]).
- * pred_out_dev  optional (d, H_d*W_d) f32 - the reference's `prediction` tensor.
+ *            features[0]).  Stream-ordered like every device argument: it must stay unchanged until the work this call enqueues
+ *            on `stream` has run (channels-last bf16 features are read in place by the propagation kernel and copied into the
+ *            ring by the kernel after it, not up front).
+ * pred_out_dev  optional (d, H_d*W_d) f32 - the reference's `prediction` tensor.  NULL in label mode lets the step skip the softmax
+ *            denominators (they do not change the arg-max): same mask, same new label.
  * mask_out_dev  optional (H, W) uint8    - the reference's per-frame mask (class indices).
  * The frame index is kept by the engine (0,1,2,... since begin_video). */
 int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* pred_out_dev,
