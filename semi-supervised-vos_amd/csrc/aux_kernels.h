@@ -284,43 +284,97 @@ __device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t*
 
 // Top-k, between the passes: per target pixel merge the sorted group-maximum lists of all partial slots (2 half-wave
 // lists per slot) and take the k-th largest value = lower bound of the k-th largest weighted exponent; also the exact
-// column max of the raw scores; zero the candidate counter.  grid = ceil(HWp/256), block = 256 (one thread per pixel).
+// column max of the raw scores; zero the candidate counter.  grid = ceil(HWp/64), block = 256 (64 pixels x 4 lanes).
+// [r2] The round-1 form walked every list with one DEPENDENT global load per entry (load, compare, break or insert: ~100 round trips
+// per pixel, 60 us for 26 blocks).  Now a partial slot's two lists are fetched whole (2 x KS independent loads in flight, the next
+// slot id with them), the merged list has KS = ceil(k/8)*8 slots like pass 1's, an insertion is one v_med3 per slot, and four lanes
+// share a pixel's slots (merged through LDS).
+template <int KS>
+__device__ __forceinline__ void topk_select_body(const float* __restrict__ part, const int* __restrict__ plist, int u0, int u1,
+                                                 int tcol, int g, float (&lst)[KS], float& M) {
+    const size_t ustride = (size_t)(1 + 2 * kTopkMax) * kBT;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) lst[i] = -3.0e38f;
+    M = -3.0e38f;
+    int slot = u0 + g < u1 ? plist[u0 + g] : 0;
+    for (int u = u0 + g; u < u1; u += 4) {       // this lane's quarter of the partial slots
+        const float* pu = part + (size_t)slot * ustride + tcol;
+        if (u + 4 < u1) slot = plist[u + 4];
+        float v[2][KS];
+        const float m = pu[0];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int i = 0; i < KS; ++i) v[hh][i] = pu[(size_t)(1 + hh * kTopkMax + i) * kBT];
+        M = fmaxf(M, m);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) {
+                const float x = v[hh][i];
+                if (x <= lst[KS - 1]) break;   // both lists are descending
+#pragma unroll
+                for (int q = KS - 1; q >= 1; --q) lst[q] = __builtin_amdgcn_fmed3f(lst[q - 1], lst[q], x);
+                lst[0] = fmaxf(lst[0], x);
+            }
+        }
+    }
+}
+
+// block = 256 = 64 target pixels x 4 lanes: every lane merges a quarter of the pixel's partial slots, lane 0 merges the four lists
+template <int KS>
+__device__ __forceinline__ void topk_select_pixel(const float* __restrict__ part, const int* __restrict__ plist_off,
+                                                  const int* __restrict__ plist, int k, int t, bool live, int col, int g,
+                                                  float (*lsts)[kTopkMax][64], float (*mred)[64], float* __restrict__ thr,
+                                                  float* __restrict__ mfin) {
+    float lst[KS], M = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) lst[i] = -3.0e38f;
+    if (live) {
+        const int tt = t / kBT, tcol = t % kBT;
+        topk_select_body<KS>(part, plist, plist_off[tt], plist_off[tt + 1], tcol, g, lst, M);
+    }
+    mred[g][col] = M;
+    if (g > 0) {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) lsts[g - 1][i][col] = lst[i];
+    }
+    __syncthreads();
+    if (g == 0 && live) {
+        for (int gg = 0; gg < 3; ++gg)
+            for (int i = 0; i < KS; ++i) {
+                const float x = lsts[gg][i][col];
+                if (x <= lst[KS - 1]) break;
+#pragma unroll
+                for (int q = KS - 1; q >= 1; --q) lst[q] = __builtin_amdgcn_fmed3f(lst[q - 1], lst[q], x);
+                lst[0] = fmaxf(lst[0], x);
+            }
+        float vk = lst[0];
+#pragma unroll
+        for (int q = 1; q < KS; ++q)
+            if (q < k) vk = lst[q];
+        thr[t] = vk;
+        mfin[t] = fmaxf(fmaxf(mred[0][col], mred[1][col]), fmaxf(mred[2][col], mred[3][col]));
+    }
+}
+
 __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ part, const int* __restrict__ plist_off,
                                                           const int* __restrict__ plist, int k, int HW, int HWp,
                                                           float* __restrict__ thr, float* __restrict__ mfin,
                                                           unsigned* __restrict__ cnt) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= HWp) return;
-    cnt[t] = 0;
-    if (t >= HW) { thr[t] = 3.0e38f; mfin[t] = 0.0f; return; }
-    const int tt = t / kBT, tcol = t % kBT;
-    const size_t ustride = (size_t)(1 + 2 * kTopkMax) * kBT;
-    float lst[kTopkMax];
-#pragma unroll
-    for (int i = 0; i < kTopkMax; ++i) lst[i] = -3.0e38f;
-    float M = -3.0e38f;
-    for (int u = plist_off[tt]; u < plist_off[tt + 1]; ++u) {
-        const float* pu = part + (size_t)plist[u] * ustride + tcol;
-        M = fmaxf(M, pu[0]);
-        for (int hh = 0; hh < 2; ++hh) {
-            for (int i = 0; i < kTopkMax; ++i) {
-                float x = pu[(size_t)(1 + hh * kTopkMax + i) * kBT];
-                if (x <= lst[kTopkMax - 1]) break;   // both lists are descending
-#pragma unroll
-                for (int q = 0; q < kTopkMax; ++q) {
-                    const float hi = fmaxf(lst[q], x);
-                    x = fminf(lst[q], x);
-                    lst[q] = hi;
-                }
-            }
-        }
+    __shared__ float lsts[3][kTopkMax][64];
+    __shared__ float mred[4][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + col;
+    if (g == 0 && t < HWp) {
+        cnt[t] = 0;
+        if (t >= HW) { thr[t] = 3.0e38f; mfin[t] = 0.0f; }
     }
-    float v = lst[0];
-#pragma unroll
-    for (int q = 1; q < kTopkMax; ++q)
-        if (q < k) v = lst[q];
-    thr[t] = v;
-    mfin[t] = M;
+    const bool live = t < HW;
+    if (k <= 8) topk_select_pixel<8>(part, plist_off, plist, k, t, live, col, g, lsts, mred, thr, mfin);
+    else if (k <= 16) topk_select_pixel<16>(part, plist_off, plist, k, t, live, col, g, lsts, mred, thr, mfin);
+    else if (k <= 24) topk_select_pixel<24>(part, plist_off, plist, k, t, live, col, g, lsts, mred, thr, mfin);
+    else topk_select_pixel<kTopkMax>(part, plist_off, plist, k, t, live, col, g, lsts, mred, thr, mfin);
 }
 
 struct TopkCombineArgs {
@@ -338,61 +392,110 @@ struct TopkCombineArgs {
 };
 
 // Top-k, after pass 2: denominators from the partials, the k largest candidates of each target pixel summed per class.
-// grid = ceil(HW/64), block = 256 (threads 0-63: one target pixel each; all 256 then pack the block's label tiles).
+// grid = ceil(HW/64), block = 256 = 64 target pixels x 4 lanes; all 256 then pack the block's label tiles.
+// [r2] Round 1 gave a pixel ONE thread: ~10 dependent partial loads, then a load per candidate, then a gather per kept candidate
+// (36 us).  Now the four lanes of a pixel take every fourth partial / candidate with their loads in flight four at a time, keep
+// private sorted lists (one v_med3 per slot), and lane 0 merges the four lists and the four per-class sums through LDS in a fixed
+// order.
+template <int KS>
+__device__ __forceinline__ void topk_list_insert(float (&lst)[KS], float x) {
+#pragma unroll
+    for (int q = KS - 1; q >= 1; --q) lst[q] = __builtin_amdgcn_fmed3f(lst[q - 1], lst[q], x);
+    lst[0] = fmaxf(lst[0], x);
+}
+
 __global__ __launch_bounds__(256) void topk_combine_kernel(const TopkCombineArgs a, float* __restrict__ pred,
                                                            uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi,
                                                            bf16_t* __restrict__ lab_lo) {
     __shared__ float outv[kMaxClasses][64];
+    __shared__ float outg[3][kMaxClasses][64];      // per-class sums of lanes 1..3 of a pixel
+    __shared__ float lsts[3][kTopkMax][64];         // sorted candidate lists of lanes 1..3
+    __shared__ float lred[4][64];                   // denominator parts, then [0] = tau
     __shared__ uint8_t clsv[64];
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        const int col = tid, t = blockIdx.x * 64 + col;
+    const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
+    const int t = blockIdx.x * 64 + col;
+    const bool live = t < a.HW;
+    if (g == 0) {
         for (int k = 0; k < a.d; ++k) outv[k][col] = 0.0f;
         clsv[col] = 0;
-        if (t < a.HW) {
-            const int tt = t / kBT, tcol = t % kBT;
-            float L = 0.0f;
-            for (int u = a.plist_off[tt]; u < a.plist_off[tt + 1]; ++u) L += a.part[((size_t)a.plist[u] * 2 + 1) * kBT + tcol];
-            unsigned n = a.cnt[t];
-            if (n > (unsigned)kTopkCap) n = kTopkCap;
-            const uint2* cd = a.cand + (size_t)t * kTopkCap;
-            // k-th largest candidate exponent (candidates are few: a register list with early-out insertion)
-            float lst[kTopkMax];
+    }
+    unsigned n = 0;
+    const uint2* cd = a.cand + (size_t)(live ? t : 0) * kTopkCap;
+    float lst[kTopkMax];
 #pragma unroll
-            for (int i = 0; i < kTopkMax; ++i) lst[i] = -3.0e38f;
-            for (unsigned i = 0; i < n; ++i) {
-                float x = __uint_as_float(cd[i].x);
-                if (x <= lst[kTopkMax - 1]) continue;
+    for (int i = 0; i < kTopkMax; ++i) lst[i] = -3.0e38f;
+    float L = 0.0f;
+    if (live) {
+        const int tt = t / kBT, tcol = t % kBT;
+        const int u0 = a.plist_off[tt], u1 = a.plist_off[tt + 1];
+        n = a.cnt[t];
+        if (n > (unsigned)kTopkCap) n = kTopkCap;
+        // this lane's quarter of the denominators: slot ids first, then the values, all in flight together
+        int sl[4];
 #pragma unroll
-                for (int q = 0; q < kTopkMax; ++q) {
-                    const float hi = fmaxf(lst[q], x);
-                    x = fminf(lst[q], x);
-                    lst[q] = hi;
-                }
-            }
-            float tau = lst[0];
+        for (int q = 0; q < 4; ++q) sl[q] = u0 + g + 4 * q < u1 ? a.plist[u0 + g + 4 * q] : -1;
 #pragma unroll
-            for (int q = 1; q < kTopkMax; ++q)
-                if (q < a.k) tau = lst[q];
-            const float mc = a.mfin[t] * a.c, inv = 1.0f / L;
-            for (unsigned i = 0; i < n; ++i) {
-                const float E = __uint_as_float(cd[i].x);
-                if (E < tau) continue;
-                const unsigned row = cd[i].y;
-                const unsigned fn = row / (unsigned)a.HWp, px = row - fn * (unsigned)a.HWp;
-                const int kcls = a.cls_ring[(size_t)a.slot[fn] * a.HWp + px];
-                if (kcls < a.d) outv[kcls][col] += __builtin_amdgcn_exp2f(E - mc) * inv;
-            }
-            int best = 0;
-            float bv = -1.0f;
-            for (int k = 0; k < a.d; ++k) {
-                const float v = outv[k][col];
-                pred[(size_t)k * a.HW + t] = v;
-                if (v > bv) { bv = v; best = k; }
-            }
-            clsv[col] = (uint8_t)best;
-            cls[t] = (uint8_t)best;
+        for (int q = 0; q < 4; ++q)
+            if (sl[q] >= 0) L += a.part[((size_t)sl[q] * 2 + 1) * kBT + tcol];
+        for (int u = u0 + g + 16; u < u1; u += 4) L += a.part[((size_t)a.plist[u] * 2 + 1) * kBT + tcol];
+        // this lane's quarter of the candidates, four loads in flight
+        for (unsigned i = g; i < n; i += 16) {
+            float x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = i + 4 * q < n ? __uint_as_float(cd[i + 4 * q].x) : -3.0e38f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (x[q] > lst[kTopkMax - 1]) topk_list_insert<kTopkMax>(lst, x[q]);
         }
+    }
+    lred[g][col] = L;
+    if (g > 0) {
+#pragma unroll
+        for (int i = 0; i < kTopkMax; ++i) lsts[g - 1][i][col] = lst[i];
+        for (int k = 0; k < a.d; ++k) outg[g - 1][k][col] = 0.0f;
+    }
+    __syncthreads();
+    if (g == 0 && live) {
+        for (int gg = 0; gg < 3; ++gg)
+            for (int i = 0; i < kTopkMax; ++i) {
+                const float x = lsts[gg][i][col];
+                if (x <= lst[kTopkMax - 1]) break;      // descending
+                topk_list_insert<kTopkMax>(lst, x);
+            }
+        float tau = lst[0];
+#pragma unroll
+        for (int q = 1; q < kTopkMax; ++q)
+            if (q < a.k) tau = lst[q];
+        const float Lt = ((lred[0][col] + lred[1][col]) + lred[2][col]) + lred[3][col];
+        lred[0][col] = tau;
+        lred[1][col] = 1.0f / Lt;
+    }
+    __syncthreads();
+    if (live) {
+        const float tau = lred[0][col], inv = lred[1][col];
+        const float mc = a.mfin[t] * a.c;
+        float (*acc)[64] = g == 0 ? outv : outg[g - 1];
+        for (unsigned i = g; i < n; i += 4) {
+            const uint2 e = cd[i];
+            const float E = __uint_as_float(e.x);
+            if (E < tau) continue;
+            const unsigned fn = e.y / (unsigned)a.HWp, px = e.y - fn * (unsigned)a.HWp;
+            const int kcls = a.cls_ring[(size_t)a.slot[fn] * a.HWp + px];
+            if (kcls < a.d) acc[kcls][col] += __builtin_amdgcn_exp2f(E - mc) * inv;
+        }
+    }
+    __syncthreads();
+    if (g == 0 && live) {
+        int best = 0;
+        float bv = -1.0f;
+        for (int k = 0; k < a.d; ++k) {
+            const float v = ((outv[k][col] + outg[0][k][col]) + outg[1][k][col]) + outg[2][k][col];
+            outv[k][col] = v;
+            pred[(size_t)k * a.HW + t] = v;
+            if (v > bv) { bv = v; best = k; }
+        }
+        clsv[col] = (uint8_t)best;
+        cls[t] = (uint8_t)best;
     }
     if (!lab_hi) return;
     __syncthreads();

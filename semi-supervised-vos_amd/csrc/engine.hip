@@ -410,7 +410,7 @@ void launch_prop(const vosprop_ctx* ctx, const LastProp& lp, hipStream_t s, hipE
     PropArgs a1 = lp.args;
     a1.part_rows = lp.rows_pass1;
     launch_prop_mode(lp, a1, 1, s);
-    hipLaunchKernelGGL(topk_select_kernel, dim3((ctx->HWp + 255) / 256), dim3(256), 0, s, lp.args.part, lp.d_off, lp.d_list,
+    hipLaunchKernelGGL(topk_select_kernel, dim3((ctx->HWp + 63) / 64), dim3(256), 0, s, lp.args.part, lp.d_off, lp.d_list,
                        lp.topk, ctx->HW, ctx->HWp, ctx->tk_thr, ctx->tk_m, ctx->tk_cnt);
     launch_prop_mode(lp, lp.args, 2, s);
 }
