@@ -301,6 +301,9 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # no launcher around us: become one.  Nothing in this process has touched a GPU yet (importing torch does not).
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    # the dispatch-attached event pairs that time the propagation kernel inside the loop cost ~1.7 us per launch they ride on:
+    # every 4th launch of the timed region carries them (96 of the default 384; `roofline.kernel_launches_timed` says how many)
+    os.environ.setdefault('VOSPROP_TIMING_STRIDE', '4')
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))

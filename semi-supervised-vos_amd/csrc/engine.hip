@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -96,6 +97,7 @@ struct vosprop_ctx {
     int up_H = 0, up_W = 0;
     float up_sy = 0.f, up_sx = 0.f;
     uint8_t* fuse_mask = nullptr;  // set by vosprop_step around propagate(): the mask combine_kernel should write
+    unsigned tseq = 0;                 // eligible launches seen since vosprop_timing_begin
     bool mask_only = false;            // set by vosprop_step around propagate(): the caller did not ask for the prediction
     const void* fuse_push = nullptr;   // set by vosprop_step around propagate(): channels-last bf16 features of the target frame that
                                        // the propagation reads in place and combine_kernel copies into the target's ring slot
@@ -495,7 +497,10 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.tk_m = ctx->tk_m;
     a.tk_cnt = ctx->tk_cnt;
     a.tk_cand = ctx->tk_cand;
-    const bool timed = ctx->timing && !f32 && !topk && !prob && !lab_lo && !lp.materialise && ctx->tev_used + 2 <= 2 * 4096;   // (either NEED_L form)
+    // in-situ timing: event pairs ride on every `stride`-th eligible launch (VOSPROP_TIMING_STRIDE, default 1 = all of them)
+    static const int tstride = getenv("VOSPROP_TIMING_STRIDE") ? std::max(1, atoi(getenv("VOSPROP_TIMING_STRIDE"))) : 1;
+    const bool eligible = ctx->timing && !f32 && !topk && !prob && !lab_lo && !lp.materialise;   // (either NEED_L form)
+    const bool timed = eligible && (ctx->tseq++ % tstride) == 0 && ctx->tev_used + 2 <= 2 * 4096;
     if (timed) {
         while (ctx->tev.size() < ctx->tev_used + 2) {
             hipEvent_t e;
@@ -1016,6 +1021,7 @@ int vosprop_timing_begin(vosprop_ctx* ctx) {
     if (!ctx) return VOSPROP_E_INVALID;
     ctx->timing = true;
     ctx->tev_used = 0;
+    ctx->tseq = 0;
     return VOSPROP_OK;
 }
 
