@@ -14,10 +14,11 @@
 //               then the rare rescale check of tile p-1, its two label MFMAs, the prior tile if the pixel tile / sigma changed,
 //               `s_waitcnt vmcnt(3)` and ONE barrier.
 //
-// Tile t lives in LDS ring slot t % 5: written by DMA during step t-3, first fragments read during step t-1, the rest and the
+// Tile t lives in LDS ring slot t % 6: written by DMA during step t-3, first fragments read during step t-1, the rest and the
 // coordinates during step t, the LABELS during step t+1 (when its label product runs - so they need no registers in between); the
-// slot is re-targeted by the DMA of step t+2, i.e. after the barrier that ends step t+1.  The loop is unrolled by two so that the
-// score accumulators of "this" and "the previous" tile swap roles without copies.
+// slot is re-targeted by the DMA of step t+3 (six slots, not five: the two waves of a SIMD keep their one barrier per step half a
+// step apart, see the main loop).  The loop is unrolled by two so that the score accumulators of "this" and "the previous" tile
+// swap roles without copies.
 #pragma once
 #include "common.h"
 #include "prop_bf16.h"
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 stile = ns;
             }
         };
-        // "tile -1" (the first step's previous tile) has probabilities 0 and takes its labels from slot 4: zero them, or stale LDS
+        // "tile -1" (the first step's previous tile) has probabilities 0 and takes its labels from the last slot: zero them, or stale LDS
         // bits that happen to spell a NaN would turn 0 x NaN into the accumulators
         float zf = 0.0f;
         asm volatile("" : "+v"(zf));
@@ -292,8 +293,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 
         f32x16 S0, S1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S1[r] = -__builtin_inff();   // "tile -1": every probability 0 (whatever labels slot 4 holds)
-        // ring slots of tile p (cur), p+1 (nxt), p-1 (prv), p+3 (stg): counters modulo 5
+        for (int r = 0; r < 16; ++r) S1[r] = -__builtin_inff();   // "tile -1": every probability 0 (whatever labels the last slot holds)
+        // ring slots of tile p (cur), p+1 (nxt), p-1 (prv), p+3 (stg): counters modulo 6
         // (kept as byte offsets into the ring)
         int s_cur = 0, s_nxt = kLdsBuf, s_prv = kRingLast, s_stg = 3 * kLdsBuf;
         auto ring_advance = [&]() __attribute__((always_inline)) {
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 sparse = sp;
             }
             // this wave's pieces of tile p+2 have landed (the 3 of tile p+3 may stay in flight); the barrier then makes every
-            // wave's pieces of p+2 visible and retires slot (p & 3) for the DMA of step p+1
+            // wave's pieces of p+2 visible and retires the slot of tile p-2 for the DMA of step p+1
             if (MAT == 1) {
                 // the score-tile stores are counted by hipcc: a __syncthreads() here would drain them every step.  Own LDS-DMA
                 // pieces of tile p+2: all but the 3 pieces and 2 stores issued in this step
