@@ -99,7 +99,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         if (ch == 32) ch = 31;
         return (unsigned)(row * 512 + ch * 16);
     };
-    const unsigned src_a = feat_src_off(wave), src_b = feat_src_off(wave + 8);
+    // [r2] kStageA (the variants without a low label part): only the OLDER wave of every SIMD (waves 0-3) stages - five pieces each:
+    // feature pieces w, w+4, w+8, w+12 and the fifth by the table above.  The older wave wins every issue arbitration and then waits
+    // at the barrier for its younger partner (stamps: ~550 cycles per step); the staging instructions are work that can move from the
+    // wave that sets the step time to the wave that has slack.
+#ifdef VOSPROP_STAGE_ALL      // A/B build: every wave stages three pieces (the mid-round scheme)
+    constexpr bool kStageA = false;
+#else
+    constexpr bool kStageA = MAT == 0 && !LAB_LO;
+#endif
+    const unsigned src_a = feat_src_off(wave), src_b = feat_src_off(kStageA ? wave + 4 : wave + 8);
+    const unsigned src_c = feat_src_off(wave + 8), src_d = feat_src_off(wave + 12);   // kStageA only
     const size_t feat_slot_stride = (size_t)A.HWp * (kC * 2);
     const unsigned char* third_base = (const unsigned char*)A.feat_ring;
     size_t third_slot_stride = feat_slot_stride;
@@ -235,6 +245,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 const int rs = stile * N + sn;      // stream index of the staged tile
                 const unsigned char* src = (const unsigned char*)A.smat + (((size_t)rs * mat_blocks + mat_cb) * 64 + lane) * 32 + i * 16;
                 glds16(src, lds + (i ? lds_b : lds_a));
+            } else if (kStageA) {
+                if (i == 0) glds16s2(src_a, so_feat, feat_base, lds, (unsigned)wave * 1024);
+                else if (i == 1) glds16s2(src_b, so_feat, feat_base, lds, ((unsigned)wave + 4) * 1024);
+                else if (i == 2) glds16s2(src_c, so_feat, feat_base, lds, ((unsigned)wave + 8) * 1024);
+                else if (i == 3) glds16s2(src_d, so_feat, feat_base, lds, ((unsigned)wave + 12) * 1024);
+                else glds16s2(third_lane, so_third, third_base, lds, third_lds);
             } else if (i == 0) glds16s2(src_a, so_feat, feat_base, lds, lds_a);
             else if (i == 1) glds16s2(src_b, so_feat, feat_base, lds, lds_b);
             else glds16s2(third_lane, so_third, third_base, lds, third_lds);
@@ -258,9 +274,15 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         stage_seek(0);
         for (int q = 0; q < 3; ++q) {   // prologue: tiles 0, 1, 2
             stage_bases();
-            stage_piece(smem_base + q * kLdsBuf, 0);
-            stage_piece(smem_base + q * kLdsBuf, 1);
-            stage_piece(smem_base + q * kLdsBuf, 2);
+            if (!kStageA || wave < kWaves / 2) {
+                stage_piece(smem_base + q * kLdsBuf, 0);
+                stage_piece(smem_base + q * kLdsBuf, 1);
+                stage_piece(smem_base + q * kLdsBuf, 2);
+                if (kStageA) {
+                    stage_piece(smem_base + q * kLdsBuf, 3);
+                    stage_piece(smem_base + q * kLdsBuf, 4);
+                }
+            }
             stage_advance();
         }
         // the target fragments are "used" HERE: their loads (issued first) fly under the prior-constant arithmetic and the staging of
@@ -328,11 +350,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 
         // one step: scores of tile p into S, softmax of tile p-1 (scores Sp, labels labp) in the gaps of the chain
         auto step = [&](auto grp, f32x16& S, const f32x16& Sp) __attribute__((always_inline)) {
-            constexpr bool MID_BARRIER = decltype(grp)::value;   // second wave of every SIMD: its barrier sits after gap 7
+            constexpr bool MID_BARRIER = (decltype(grp)::value & 1) != 0;   // second wave of every SIMD: its barrier sits after gap 7
+            constexpr bool STAGER = (decltype(grp)::value & 2) == 0;        // this wave issues LDS-DMA pieces
             const unsigned char* lb = smem + s_cur;
             const unsigned char* lbn = smem + s_nxt;
             const unsigned b_st = smem_base + (unsigned)s_stg;
-            stage_bases();
+            if (STAGER) stage_bases();
             LabFrag<LAB_LO> labp;
             const float mc = st.m * c;
             float lt0 = NEED_L ? 0.0f : kNegBig, lt1 = 0.0f, qprev = 0.0f;
@@ -367,7 +390,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #endif
                 }
 #if !(VOSPROP_DABLATE & 4)
-                if (ks == 2 || ks == 7 || ks == 12) stage_piece(b_st, ks / 5);
+                if (STAGER) {
+                    if (kStageA) { if (ks % 3 == 1) stage_piece(b_st, ks / 3); }      // gaps 1, 4, 7, 10, 13: pieces 0..4
+                    else if (ks == 2 || ks == 7 || ks == 12) stage_piece(b_st, ks / 5);
+                }
 #endif
                 if (MAT == 1) continue;                        // score tiles only
                 if (ks == 10) labp.load(smem + s_prv, lane);   // labels of tile p-1, for the label MFMAs after the chain
@@ -406,7 +432,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 }
                 if (MID_BARRIER && ks == 7) {
                     // this wave's pieces of tile p+2 (issued in step p-1) have landed: only the two of this step may be in flight
-                    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+                    if (STAGER) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+                    else asm volatile("s_barrier" ::: "memory");      // nothing of this wave's is in flight
                 }
 #ifndef VOSPROP_DENSE_NO_SGB
                 // pin the interleave (cdna guide T19): after each score MFMA its fragment refill and the 4-5 VALU instructions
@@ -422,7 +449,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #ifdef VOSPROP_STAMP
             STAMP_AT(2);   // 2: gaps 8-15
 #endif
-            stage_advance();
+            if (STAGER) stage_advance();
             if (MAT != 1) finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
 #ifdef VOSPROP_STAMP
             STAMP_AT(3);   // 3: rescale check + label MFMAs
@@ -480,7 +507,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 STAMP_AT(4);   // 4: tail mask, prior tile, cursor
 #endif
                 if (!MID_BARRIER) {
-                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    if (STAGER && kStageA) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                    else if (STAGER) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 #ifdef VOSPROP_STAMP
                     STAMP_AT(5);   // 5: wait for the own pieces of tile p+2
 #endif
@@ -506,13 +534,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         // first group's pieces would overtake the second group's label reads - hence six).
         constexpr bool kSkew = MAT == 0;
         const bool grp_b = kSkew && wave >= kWaves / 2 && !A.no_skew;
-        typedef std::integral_constant<bool, false> GrpA;
-        typedef std::integral_constant<bool, true> GrpB;
+        // step forms: bit 0 = barrier after gap 7, bit 1 = this wave does not stage
+        typedef std::integral_constant<int, 0> GrpA;                       // waves 0-3 (and everybody in the old scheme)
+        typedef std::integral_constant<int, kStageA ? 3 : 1> GrpB;         // waves 4-7, skewed
+        typedef std::integral_constant<int, kStageA ? 2 : 0> GrpBflat;     // waves 4-7 with VOSPROP_DENSE_SKEW=0
+        const bool second = wave >= kWaves / 2;
         int p = 0;
         if (grp_b) {
             for (; p + 1 < n_steps; p += 2) {
                 step(GrpB(), S0, S1);
                 step(GrpB(), S1, S0);
+            }
+        } else if (kStageA && second) {
+            for (; p + 1 < n_steps; p += 2) {
+                step(GrpBflat(), S0, S1);
+                step(GrpBflat(), S1, S0);
             }
         } else {
             for (; p + 1 < n_steps; p += 2) {
@@ -538,6 +574,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         };
         if (p < n_steps) {
             if (grp_b) step(GrpB(), S0, S1);
+            else if (kStageA && second) step(GrpBflat(), S0, S1);
             else step(GrpA(), S0, S1);
             if (MAT != 1) drain(S0);
         } else {
