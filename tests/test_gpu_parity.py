@@ -358,3 +358,35 @@ def test_mask_only_steps_equal_steps_that_return_the_prediction(vos, dev, layout
     for a, b in zip(masks[True], masks[False]):
         assert torch.equal(a, b), float((a != b).float().mean())
     assert len({int(m.sum()) for m in masks[False]}) > 1
+
+
+def test_step_writes_the_mask_into_a_caller_buffer(vos, dev):
+    """engine.step(mask_out=...) writes the mask into the caller's (H, W) uint8 buffer (a slice of a batch buffer that goes back to
+    the host in one copy, bench.py end_to_end) - the same mask a plain step returns; a buffer of the wrong shape is refused."""
+    H, W = 96, 136
+    Hd, Wd = vos.feature_map_size(H, W)
+    rs = np.random.RandomState(5)
+    ann = np.zeros((H, W), np.uint8)
+    ann[10:50, 20:90] = 1
+    feats = [torch.from_numpy(rs.randn(256, Hd, Wd).astype(np.float32) * 0.25).to(dev) for _ in range(5)]
+    ref = []
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=9)
+    eng.begin_video(ann)
+    for f in feats:
+        _, m = eng.step(f, want_pred=False, want_mask=True)
+        ref.append(m)
+    eng.close()
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=9)
+    eng.begin_video(ann)
+    batch = torch.full((len(feats), H, W), 255, dtype=torch.uint8, device=dev)
+    for i, f in enumerate(feats):
+        _, m = eng.step(f, want_pred=False, mask_out=batch[i])
+        assert (m is None) == (i == 0)
+        if i:
+            assert m.data_ptr() == batch[i].data_ptr()
+    with pytest.raises(ValueError):
+        eng.step(feats[0], mask_out=torch.empty((H, W + 1), dtype=torch.uint8, device=dev))
+    eng.close()
+    assert bool((batch[0] == 255).all())
+    for i in range(1, len(feats)):
+        assert torch.equal(batch[i], ref[i])
