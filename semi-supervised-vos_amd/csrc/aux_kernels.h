@@ -130,8 +130,8 @@ __device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t*
 //   out[k,t] = sum_u Y_u[k] 2^((m_u - M) c) / sum_u l_u 2^((m_u - M) c)      (reference predict.py:55-70)
 //   cls[t]   = argmax_k out[k,t], first maximum wins (reference inference_utils.py:70, torch.argmax on CPU)
 //   new label of the frame = one-hot(cls) or out itself in probability mode   (inference_utils.py:67-71)
-// The partial slots that hold target tile tt are listed in CSR form (plist_off[tt] .. plist_off[tt+1]); the host derives
-// them from the same WorkMap the propagation kernel uses.
+// The partial slots that hold target tile tt are slots plist_off[tt] .. plist_off[tt+1] - 1: the host numbers the slots of a
+// tile consecutively (engine.hip get_plan), so the slot list itself (plist) is the identity and is not read.
 // grid = ceil(HW/64), block = 256 = 64 target pixels x 4 partial lanes (each lane folds every 4th partial with its own
 // running max; the 4 lanes are merged through LDS), then the block's two 32-pixel label tiles are packed (256 chunks).
 // Optional tail of combine_kernel: the nearest up-sampling of the block's 64 class indices into the full-size mask (reference
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < kPre; ++q) {
         const int u = u0 + g + 4 * q;
-        sl[q] = u < u1 ? plist[u] : -1;
+        sl[q] = u < u1 ? u : -1;          // slots of a target tile are consecutive (engine.hip get_plan): plist is the identity
     }
     float pm[kPre], pl[kPre], pa[kPre][kMaxClasses];
 #pragma unroll
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
         M = Mn;
     }
     for (int u = u0 + g + 4 * kPre; u < u1; u += 4) {
-        const float* pu = part + (size_t)plist[u] * ustride + tcol;
+        const float* pu = part + (size_t)u * ustride + tcol;
         const float m = pu[0];
         const float Mn = fmaxf(M, m);
         const float so = __builtin_amdgcn_exp2f((M - Mn) * c), sn = __builtin_amdgcn_exp2f((m - Mn) * c);
@@ -296,10 +296,9 @@ __device__ __forceinline__ void topk_select_body(const float* __restrict__ part,
 #pragma unroll
     for (int i = 0; i < KS; ++i) lst[i] = -3.0e38f;
     M = -3.0e38f;
-    int slot = u0 + g < u1 ? plist[u0 + g] : 0;
-    for (int u = u0 + g; u < u1; u += 4) {       // this lane's quarter of the partial slots
-        const float* pu = part + (size_t)slot * ustride + tcol;
-        if (u + 4 < u1) slot = plist[u + 4];
+    for (int u = u0 + g; u < u1; u += 4) {       // this lane's quarter of the partial slots (slots of a target tile are consecutive,
+                                                 // engine.hip get_plan: the slot list is the identity and is not read)
+        const float* pu = part + (size_t)u * ustride + tcol;
         float v[2][KS];
         const float m = pu[0];
 #pragma unroll
@@ -433,11 +432,11 @@ __global__ __launch_bounds__(256) void topk_combine_kernel(const TopkCombineArgs
         // this lane's quarter of the denominators: slot ids first, then the values, all in flight together
         int sl[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sl[q] = u0 + g + 4 * q < u1 ? a.plist[u0 + g + 4 * q] : -1;
+        for (int q = 0; q < 4; ++q) sl[q] = u0 + g + 4 * q < u1 ? u0 + g + 4 * q : -1;     // (identity slot list)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (sl[q] >= 0) L += a.part[((size_t)sl[q] * 2 + 1) * kBT + tcol];
-        for (int u = u0 + g + 16; u < u1; u += 4) L += a.part[((size_t)a.plist[u] * 2 + 1) * kBT + tcol];
+        for (int u = u0 + g + 16; u < u1; u += 4) L += a.part[((size_t)u * 2 + 1) * kBT + tcol];
         // this lane's quarter of the candidates, four loads in flight
         for (unsigned i = g; i < n; i += 16) {
             float x[4];

@@ -274,14 +274,20 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
     std::vector<std::vector<Segment>> per_wg;
     p.wg_per_xcd = build_segments(TT, NT, streamk, per_wg);
     p.grid = kXcd * p.wg_per_xcd;
+    // Partial slots are numbered so that the slots of one target tile are CONSECUTIVE: slot = off[tt] + (its rank among the tile's
+    // segments).  The kernels that merge partials then need `off` only - the slot list is the identity and they do not load it (one
+    // dependent round trip fewer in combine_kernel / topk_select_kernel / topk_combine_kernel).
+    std::vector<int> off((size_t)TT + 1, 0);
+    for (int b = 0; b < p.grid; ++b)
+        for (const Segment& sg : per_wg[(size_t)b]) ++off[(size_t)sg.tt + 1];
+    for (int tt = 0; tt < TT; ++tt) off[(size_t)tt + 1] += off[(size_t)tt];
+    std::vector<int> next(off.begin(), off.end() - 1);
     std::vector<Segment> segs;
     std::vector<int> seg_off((size_t)p.grid + 1, 0);
-    std::vector<std::vector<int>> lists((size_t)TT);
     for (int b = 0; b < p.grid; ++b) {
         int steps = 0;
         for (Segment sg : per_wg[(size_t)b]) {
-            sg.slot = (int)segs.size();
-            lists[(size_t)sg.tt].push_back(sg.slot);
+            sg.slot = next[(size_t)sg.tt]++;
             segs.push_back(sg);
             steps += sg.n_steps;
         }
@@ -289,11 +295,8 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
         seg_off[(size_t)b + 1] = (int)segs.size();
     }
     p.n_parts = (int)segs.size();
-    std::vector<int> off((size_t)TT + 1, 0), flat;
-    for (int tt = 0; tt < TT; ++tt) {
-        off[(size_t)tt + 1] = off[(size_t)tt] + (int)lists[(size_t)tt].size();
-        flat.insert(flat.end(), lists[(size_t)tt].begin(), lists[(size_t)tt].end());
-    }
+    std::vector<int> flat((size_t)p.n_parts);
+    for (int i = 0; i < p.n_parts; ++i) flat[(size_t)i] = i;      // identity (kept for the kernels' signatures and the tests)
     HIP_TRY(ctx, hipMalloc((void**)&p.d_off, off.size() * sizeof(int)));
     HIP_TRY(ctx, hipMalloc((void**)&p.d_list, (flat.size() + 1) * sizeof(int)));
     HIP_TRY(ctx, hipMalloc((void**)&p.d_segs, (segs.size() + 1) * sizeof(Segment)));
