@@ -179,6 +179,15 @@ int vosprop_bias_relu_maxpool(const void* x, const void* bias, void* y, int n, i
 int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, const void* residual, void* y,
                            long long pixels, int cin, int cout, int relu, int dtype, void* stream);
 
+/* Reproducible mode, process-wide (also switched on by VOSPROP_DETERMINISTIC=1 in the environment): vosprop_pointwise_conv then
+ * picks, for every problem, the FIRST candidate in the library's own rank order that passes the numerical gate - no timing race
+ * between candidates, no cache file read or written - so the kernel of a layer is a pure function of the problem and two processes
+ * (a one-process run and the shards of `main.py inference --gpus N --deterministic`) compute the same bits.  The propagation kernels
+ * themselves are deterministic in every mode (fixed work map, partials merged in a fixed order, no atomics on the dense path).
+ * The reference has no such switch: its videos are independent (src/utils/inference_utils.py:28-48), which is what makes "sharded
+ * output == single-process output" a byte-level statement.  Returns the previous setting. */
+int vosprop_set_deterministic(int on);
+
 /* Frame sampler, reference `sample_frames` (src/model/predict.py:74-89).  Host-side, exact.
  * out must hold max(num_refs, 3) ints (or frame_idx when frame_idx <= num_refs); returns the count - for num_refs == 3 past
  * frame 3 that is the 3 "continuous" frames alone.  num_refs < 3 past frame num_refs: VOSPROP_E_INVALID (the reference's

@@ -56,6 +56,7 @@ SYMBOLS = {
     'vosprop_pointwise_conv': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, _vp]),
     'vosprop_frame_index': (ctypes.c_int, [_vp]),
+    'vosprop_set_deterministic': (ctypes.c_int, [ctypes.c_int]),
     'vosprop_predict': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_int, _vp, _vp]),

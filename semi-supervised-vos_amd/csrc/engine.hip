@@ -688,6 +688,13 @@ int vosprop_pointwise_conv(const void* x, const void* weight, const void* bias, 
     }
 }
 
+int vosprop_set_deterministic(int on) {
+    std::lock_guard<std::mutex> lock(pw_mutex());
+    const int prev = pw_deterministic_flag();
+    pw_deterministic_flag() = on ? 1 : 0;
+    return prev;
+}
+
 /* test hook (GPU): every candidate algorithm the library returns for one pointwise-convolution problem, each timed and checked
  * against the f32 reference of csrc/pointwise.h on a zeroed and on a 0xFF-filled workspace.  rows: vosprop::PwCandidateReport
  * (index, workspace bytes, microseconds, worst err/tol clean, worst err/tol dirty, repeats, repeats_bad, name[160]).  `repeats`

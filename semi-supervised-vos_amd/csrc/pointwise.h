@@ -29,6 +29,7 @@
 #include <hipblaslt/hipblaslt-ext.hpp>
 
 #include <fcntl.h>
+#include <sys/file.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -122,7 +123,7 @@ struct PwDevice {
     size_t gate_elems = 0;
     unsigned* worst = nullptr;
     std::string ident;     // device name + library version, for the cache key
-    // (pixels, cin, cout, dtype, epilogue, residual) -> plan
+    // (pixels, cin, cout, dtype, epilogue, residual + 2 * deterministic mode) -> plan
     std::map<std::tuple<long long, int, int, int, int, int>, PwPlan> plans;
 };
 
@@ -130,8 +131,7 @@ inline std::mutex& pw_mutex() { static std::mutex m; return m; }
 inline std::map<int, PwDevice>& pw_devices() { static std::map<int, PwDevice> d; return d; }
 
 // The validated winner's library solution index, per exact problem, remembered across processes ($VOSPROP_CACHE_DIR or
-// ~/.cache/vosprop; VOSPROP_PW_CACHE=0 turns it off).  One text line per entry, appended with a single write (safe with one
-// process per GPU).  An entry is a hint only: it is re-validated before use.
+// ~/.cache/vosprop; VOSPROP_PW_CACHE=0 turns it off).  One text line per entry, appended with a single write under flock.  An entry is a hint only: it is re-validated before use.
 struct PwAlgoCache {
     bool loaded = false, enabled = true;
     std::string file;
@@ -166,7 +166,9 @@ inline void pw_algo_cache_store(PwAlgoCache& c, const std::string& key, int idx)
     const std::string line = key + " " + std::to_string(idx) + "\n";
     const int fd = open(c.file.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
     if (fd < 0) return;
+    (void)flock(fd, LOCK_EX);      // the shards of a `--gpus N` run append to the same file
     (void)!write(fd, line.data(), line.size());
+    (void)flock(fd, LOCK_UN);
     close(fd);
 }
 
@@ -187,6 +189,14 @@ inline int pw_candidates() {      // VOSPROP_PW_CANDIDATES: how many of the libr
     return n;
 }
 inline bool pw_verbose() { static const bool v = getenv("VOSPROP_PW_VERBOSE") != nullptr; return v; }
+// Deterministic mode (vosprop_set_deterministic / VOSPROP_DETERMINISTIC=1; `main.py inference --deterministic`): the algorithm of a
+// problem is a pure function of the problem - the FIRST candidate in the library's own rank order that passes the numerical gate,
+// no timing race, no cache file - so that two processes (a one-process run and the shards of a `--gpus N` run) use the same
+// kernel for the same layer and produce the same bits.
+inline int& pw_deterministic_flag() {
+    static int f = [] { const char* e = getenv("VOSPROP_DETERMINISTIC"); return e && e[0] != '0' ? 1 : 0; }();
+    return f;
+}
 
 inline float pw_eps_out(int dtype_key) {   // two roundings of the output type (VOSPROP_DT_*: 0 f32, 1 f16, 2 bf16)
     return dtype_key == 2 ? 0.0078125f : dtype_key == 1 ? 0.0009765625f : 4.76837158e-7f;
@@ -299,7 +309,8 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
         D.ident += ":lt" + std::to_string(ver);
     }
     const int ep_key = (bias ? 1 : 0) | (relu ? 2 : 0);
-    PwPlan& P = D.plans[std::make_tuple(pixels, cin, cout, dtype_key, ep_key, residual ? 1 : 0)];
+    const bool det = pw_deterministic_flag() != 0 && !report;
+    PwPlan& P = D.plans[std::make_tuple(pixels, cin, cout, dtype_key, ep_key, (residual ? 1 : 0) + (det ? 2 : 0))];
     if (P.dead && !report) return 3;
     if (!P.ok && capturing) return 3;   // nothing is tuned or validated inside a capture: the caller takes the convolution path
     if (!D.workspace) {
@@ -386,7 +397,7 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
         size_t best_ws = 0;
         float best_ms = 1e30f;
         // ---- a remembered algorithm: ask the library whether it still serves this problem, then re-validate it ----
-        if (!report && AC.enabled) {
+        if (!report && AC.enabled && !det) {
             auto it = AC.index.find(ckey);
             if (it != AC.index.end()) {
                 std::vector<int> idx{it->second};
@@ -467,13 +478,14 @@ inline int pointwise_conv(const void* x, const void* w, const void* bias, const 
                     best_index = hipblaslt_ext::getIndexFromAlgo(res[i].algo);
                     have = true;
                 }
+                if (det && have) break;      // deterministic mode: the first gated candidate in rank order, whatever its time
             }
             if (pw_verbose())
                 fprintf(stderr, "[vosprop] pointwise %lld x %d -> %d (bias %d relu %d residual %d): %d candidates, %d rejected by the gate, algo %d wins, %.1f us\n",
                         pixels, cin, cout, bias ? 1 : 0, relu ? 1 : 0, residual ? 1 : 0, got, n_rejected, best_index, best_ms * 1e3f);
             if (report) return 0;
             if (!have) { P.dead = true; return 3; }
-            pw_algo_cache_store(AC, ckey, best_index);
+            if (!det) pw_algo_cache_store(AC, ckey, best_index);
         }
         // the winner's own workspace, zeroed once (stream-ordered before its first launch)
         if (best_ws) {

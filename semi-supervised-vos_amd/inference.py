@@ -66,18 +66,38 @@ _DTYPES = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': None}
                    'search per shape at start-up: for long jobs).')
 @click.option('--encoder-graph/--no-encoder-graph', default=True,
               help='[engine] replay the encoder forward of full batches as one captured HIP graph.')
+@click.option('--deterministic/--no-deterministic', default=False,
+              help='[engine] reproducible masks: MIOpen restricted to its deterministic solvers (no atomic split-K), the pointwise-GEMM '
+                   'algorithm of a layer a pure function of the problem (no timing race, no cache), encoder batches cut at video '
+                   'boundaries. A --gpus N run then writes byte-identical PNGs to a one-process run (videos are independent, '
+                   'reference inference_utils.py:28-48).')
 @click.option('--shard', type=(int, int), default=(0, 1), hidden=True, help='[engine] internal: rank, world')
 def inference_command(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                       inference_strategy, additional_model, additional_model_type, probability, scale, fusion, gpus,
                       encoder_dtype, propagation_precision, encoder_batch, io_workers, png_workers, miopen_find, encoder_graph,
-                      shard):
+                      deterministic, shard):
     if gpus > 1 and shard == (0, 1):
         return _launch_shards(gpus)
     inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_model, additional_model_type, probability, scale, fusion,
                            encoder_dtype=encoder_dtype, shard=shard, encoder_batch=encoder_batch, io_workers=io_workers,
                            png_workers=png_workers, encoder_graph=encoder_graph, miopen_find=miopen_find,
-                           propagation_precision=propagation_precision)
+                           propagation_precision=propagation_precision, deterministic=deterministic)
+
+
+def set_deterministic(on=True):
+    """Process-wide reproducible mode of the encoder (measured with tools/determinism_probe.py):
+      * torch.backends.cudnn.deterministic -> MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC on every convolution descriptor: MIOpen leaves
+        out the solvers that split the reduction over workgroups and accumulate with atomics (the f16 3x3 convolutions of small
+        maps: 10-24 % of their outputs differ from one launch to the next without it);
+      * vosprop_set_deterministic: the pointwise-GEMM algorithm of a layer is the first gated candidate in the library's rank
+        order - no timing race between candidates, no cache file - so every process picks the same kernel.
+    The propagation kernels need nothing: fixed work map, partials merged in a fixed order, no atomics on the dense path."""
+    from . import _native
+    torch.backends.cudnn.deterministic = bool(on)
+    if on:
+        torch.backends.cudnn.benchmark = False
+    _native.lib().vosprop_set_deterministic(1 if on else 0)
 
 
 def visible_devices(n):
@@ -120,7 +140,11 @@ def _launch_shards(gpus):
 def inference_command_impl(ref_num, data, resume, model, temperature, frame_range, sigma_1, sigma_2, save, device,
                            inference_strategy, additional_resume, additional_model_type, probability_propagation, scale,
                            reduction, disable=False, encoder_dtype='f16', shard=(0, 1), encoder_batch=32, io_workers=None,
-                           png_workers=2, encoder_graph=True, miopen_find=False, propagation_precision='bf16'):
+                           png_workers=2, encoder_graph=True, miopen_find=False, propagation_precision='bf16',
+                           deterministic=False):
+    if deterministic:
+        set_deterministic(True)
+        miopen_find = False        # a timed solver search is a race between solvers: its winner can differ from process to process
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)
     if Config.DEVICE.type == 'cuda':
@@ -166,7 +190,7 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
         head = (loader, len(dataset), annotation_dir, last_video, save, sigma_1, sigma_2, frame_range, ref_num,
                 temperature, probability_propagation)
         opts = dict(encoder_dtype=dtype, stats=stats, encoder_batch=encoder_batch, png_workers=png_workers,
-                    precision={'bf16': 0, 'f32': 1}[propagation_precision])
+                    precision={'bf16': 0, 'f32': 1}[propagation_precision], align_videos=deterministic)
         if inference_strategy == 'single':
             inference_single(net, *head, disable, **opts)
         elif inference_strategy == 'hor-flip':

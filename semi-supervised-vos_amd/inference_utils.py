@@ -23,7 +23,7 @@ def _read_annotation(path):
     return np.asarray(ann), ann.getpalette(), ann
 
 
-def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None):
+def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None, align_videos=False):
     """Encoder look-ahead for every strategy: yields ([features (1,C,H_d,W_d) per branch], video_name) in loader order, but
     runs each encoder on `batch` consecutive frames at a time - the features do not depend on the propagated labels (only the
     labels are sequential) nor on the video, and the encoder is ~3.5x cheaper per frame at batch 16 than at batch 1 on
@@ -31,7 +31,10 @@ def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None):
     to `batch` frames: every new batch size costs MIOpen look-ups, a GEMM plan and a graph capture - far more than encoding a
     few frames too many - so the encoder only ever sees ONE shape per frame size.  `models`: one encoder per branch.  A loader item carries one tensor (every branch sees it) or one
     tensor per branch (the flip / 2-scale datasets).  `resize(H, W) -> (h, w)`: nearest pre-scaling of the input, the
-    3-scale strategy's (reference inference_utils.py:523-526)."""
+    3-scale strategy's (reference inference_utils.py:523-526).  align_videos (`--deterministic`): a batch also ends where the video
+    changes, so the position of a frame inside its encoder batch depends on its index in its video only - whichever other videos
+    the process was given (a library GEMM may split tiles differently along the batch; measured position-independent on this
+    stack, but nothing promises it)."""
     nb = len(models)
     pend = [[] for _ in range(nb)]
     names = []
@@ -81,7 +84,8 @@ def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None):
         ins = list(input) if isinstance(input, (list, tuple)) else [input] * nb
         if len(ins) != nb:
             raise ValueError(f'loader item carries {len(ins)} inputs, the strategy has {nb} branches')
-        if names and (len(names) == batch or any(ins[b].shape != pend[b][-1].shape for b in range(nb))):
+        if names and (len(names) == batch or any(ins[b].shape != pend[b][-1].shape for b in range(nb))
+                      or (align_videos and name != names[-1])):
             yield from flush()
         for b in range(nb):
             pend[b].append(ins[b])
@@ -90,15 +94,15 @@ def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None):
         yield from flush()
 
 
-def encoded_frames(model, loader, device, encoder_dtype, batch):
+def encoded_frames(model, loader, device, encoder_dtype, batch, align_videos=False):
     """Single-branch form: yields (features (1,C,H_d,W_d), video_name)."""
-    for feats, name in encoded_branches([model], loader, device, encoder_dtype, batch):
+    for feats, name in encoded_branches([model], loader, device, encoder_dtype, batch, align_videos=align_videos):
         yield feats[0], name
 
 
 def inference_single(model, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                      frame_range, ref_num, temperature, probability_propagation, disable, encoder_dtype=None,
-                     stats=None, encoder_batch=32, png_workers=2, precision=0):
+                     stats=None, encoder_batch=32, png_workers=2, precision=0, align_videos=False):
     """precision: VOSPROP_PREC_* of the propagation (0 = bf16 MFMA, 1 = the f32 parity path).
     stats (optional dict) receives {'frames', 'videos', 'seconds'} for the fps report."""
     import time
@@ -121,7 +125,7 @@ def inference_single(model, inference_loader, total_len, annotation_dir, last_vi
             writer.submit(video, palette, masks)     # D2H + PNG encoding proceed while the next video is processed
             masks.clear()
 
-    stream = encoded_frames(model, inference_loader, device, encoder_dtype, max(1, encoder_batch))
+    stream = encoded_frames(model, inference_loader, device, encoder_dtype, max(1, encoder_batch), align_videos)
     for features, current_video in tqdm(stream, total=total_len, disable=disable):
         if current_video != last_video:
             flush(last_video)
@@ -245,7 +249,7 @@ def fuse_two(a, b, probability, reduction_str, unflip):
 
 def _inference_two_branch(strategy, models, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                           frame_range, ref_num, temperature, probability_propagation, scale, reduction_str, disable,
-                          encoder_dtype=None, stats=None, encoder_batch=32, png_workers=2, precision=0):
+                          encoder_dtype=None, stats=None, encoder_batch=32, png_workers=2, precision=0, align_videos=False):
     import time
     from tqdm import tqdm
     spec = _TWO_BRANCH[strategy]
@@ -267,7 +271,7 @@ def _inference_two_branch(strategy, models, inference_loader, total_len, annotat
             writer.submit(video, palette, masks)
             masks.clear()
 
-    stream = encoded_branches(models, inference_loader, device, encoder_dtype, max(1, encoder_batch))
+    stream = encoded_branches(models, inference_loader, device, encoder_dtype, max(1, encoder_batch), align_videos=align_videos)
     for feats, current_video in tqdm(stream, total=total_len, disable=disable):
         if current_video != last_video:
             flush(last_video)
@@ -336,7 +340,8 @@ def inference_multimodel(model, additional_model, inference_loader, total_len, a
 
 def inference_3_scale(model, inference_loader, total_len, annotation_dir, last_video, save, sigma_1, sigma_2,
                       frame_range, ref_num, temperature, probability_propagation, scale, disable, encoder_dtype=None,
-                      stats=None, encoder_batch=32, output_size=THREE_SCALE_OUTPUT, png_workers=2, precision=0):
+                      stats=None, encoder_batch=32, output_size=THREE_SCALE_OUTPUT, png_workers=2, precision=0,
+                      align_videos=False):
     """reference inference_utils.py:514-595: three full passes over the loader at input scales [0.9, 1.0, scale] (nearest
     pre-scaling of the normalised image), each a single chain whose class maps are produced at `output_size` (the
     reference hard-codes 480x910 whatever the video size); the saved mask is the element-wise maximum of the three class
@@ -361,7 +366,8 @@ def inference_3_scale(model, inference_loader, total_len, annotation_dir, last_v
                 per_video.setdefault(video, []).append(torch.stack(masks).cpu().numpy())
                 masks.clear()
 
-        stream = encoded_branches([model], inference_loader, device, encoder_dtype, max(1, encoder_batch), resize=resize)
+        stream = encoded_branches([model], inference_loader, device, encoder_dtype, max(1, encoder_batch), resize=resize,
+                                  align_videos=align_videos)
         for feats, current_video in tqdm(stream, total=total_len, disable=disable):
             if prev is not None and current_video != prev:
                 flush(prev)

@@ -21,17 +21,21 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-# Order of the files under `-x`: the hot path first (operator parity, roll-outs, CLI, strategies,
-# look-ahead), then the rows either side of it (encoder, host pipeline).  A failure in a "next" row can then never hide the
+# Order of the files under `-x`: the hot path first (operator parity, roll-outs, full-size configs, the
+# strategies against the reference's own goldens, look-ahead - all fed with fixed features, nothing in them depends on a library's
+# choice of kernel), then the CLI end to end (encoder on noise frames: tolerance tests), then the rows either side of the path
+# (host pipeline, encoder).  A failure in a "next" row can then never hide the
 # evidence for the path itself (which is what happened to the round-1 driver run).
-_FILE_ORDER = ['test_oracle_golden.py', 'test_gpu_parity.py', 'test_gpu_precision.py', 'test_gpu_configs.py', 'test_gpu_cli.py',
-               'test_gpu_strategies.py', 'test_gpu_lookahead.py', 'test_host.py', 'test_metrics.py', 'test_bench_launcher.py',
-               'test_encoder.py']
+_FILE_ORDER = ['test_oracle_golden.py', 'test_gpu_parity.py', 'test_gpu_precision.py', 'test_gpu_topk.py', 'test_gpu_configs.py',
+               'test_gpu_strategies.py', 'test_gpu_lookahead.py', 'test_gpu_cli.py', 'test_host.py', 'test_metrics.py',
+               'test_bench_launcher.py', 'test_encoder.py']
 
 
 def pytest_collection_modifyitems(session, config, items):
     def key(item):
         name = Path(str(item.fspath)).name
+        if 'config4_thirty_videos' in item.name:      # a multi-process CLI test: it runs with the CLI tests, after the strategies
+            name = 'test_gpu_cli.py'
         return _FILE_ORDER.index(name) if name in _FILE_ORDER else len(_FILE_ORDER) - 1
     items.sort(key=key)          # stable: the order inside a file is kept
 

@@ -182,8 +182,12 @@ def test_inference_cli_multimodel_and_three_scale(tmp_path):
 
 
 def test_inference_cli_sharded_over_two_processes(tmp_path):
-    """`--gpus 2`: one child process per shard (here both on GPU 0 via VOSPROP_SHARD_DEVICES), whole videos dealt out by LPT, the
-    parent sums the per-shard statistics; every video's masks agree with the single-process run's."""
+    """`--gpus 2 --deterministic`: one child process per shard (here both on GPU 0 via VOSPROP_SHARD_DEVICES), whole videos dealt out
+    by LPT, the parent sums the per-shard statistics; every PNG of the sharded run is BYTE-IDENTICAL to the one-process run's
+    (SURVEY.md section 4 tier iii: videos are independent in the reference, src/utils/inference_utils.py:28-48, so sharding
+    correctness is equality, not a tolerance).  Default encoder precision (f16, the reference's autocast).  Without
+    --deterministic the two runs differ in ~1 % of the pixels of this noise dataset: MIOpen's f16 3x3 convolutions of small maps
+    are not reproducible from launch to launch (tools/determinism_probe.py)."""
     import os
     from PIL import Image
     vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
@@ -191,7 +195,7 @@ def test_inference_cli_sharded_over_two_processes(tmp_path):
     torch.manual_seed(0)
     torch.save({'state_dict': vn.VOSNet('resnet18').state_dict()}, tmp_path / 'ckpt.pth.tar')
     base = [sys.executable, 'main.py', 'inference', '-d', str(tmp_path / 'data'), '-r', str(tmp_path / 'ckpt.pth.tar'), '-m',
-            'resnet18', '--ref_num', '5', '--frame_range', '6']
+            'resnet18', '--ref_num', '5', '--frame_range', '6', '--deterministic']
     one = subprocess.run(base + ['-s', str(tmp_path / 'one')], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run(base + ['-s', str(tmp_path / 'two'), '--gpus', '2'], cwd=ROOT, capture_output=True, text=True, timeout=900,
@@ -199,11 +203,31 @@ def test_inference_cli_sharded_over_two_processes(tmp_path):
     assert two.returncode == 0, two.stderr[-2000:]
     summary = json.loads(two.stdout.strip().splitlines()[-1])
     assert summary['gpus'] == 2 and summary['frames'] == 18
-    # not bit-equal by construction: MIOpen's split-K convolutions accumulate with atomics, so the bf16 encoder output - and on
-    # this random-init / noise dataset a few near-tied pixels - differ from process to process
     for vid in ('bear', 'camel'):
-        a = np.stack([np.asarray(Image.open(tmp_path / 'one' / vid / f'{i:05d}.png')) for i in range(9)])
-        b = np.stack([np.asarray(Image.open(tmp_path / 'two' / vid / f'{i:05d}.png')) for i in range(9)])
-        assert np.array_equal(a[0], b[0])
-        diff = float(np.mean(a != b))
-        assert diff <= 0.01, f'{vid}: {diff * 100:.2f} % of pixels differ'
+        for i in range(9):
+            a = np.asarray(Image.open(tmp_path / 'one' / vid / f'{i:05d}.png'))
+            b = np.asarray(Image.open(tmp_path / 'two' / vid / f'{i:05d}.png'))
+            assert np.array_equal(a, b), f'{vid}/{i:05d}.png: {np.mean(a != b) * 100:.3f} % of pixels differ'
+        # the masks are not degenerate: more than one class survives to the last frame
+        assert len(np.unique(np.asarray(Image.open(tmp_path / 'two' / vid / '00008.png')))) >= 2
+
+
+def test_deterministic_runs_repeat_bit_for_bit(tmp_path):
+    """Two one-process `--deterministic` runs of the same job write identical PNGs, and `vosprop_set_deterministic` reports its
+    previous state (the switch is process-wide)."""
+    from PIL import Image
+    vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
+    native = importlib.import_module('semi-supervised-vos_amd._native')
+    assert native.lib().vosprop_set_deterministic(1) in (0, 1)
+    assert native.lib().vosprop_set_deterministic(0) == 1
+    _make_dataset(tmp_path / 'data', n_frames=7)
+    torch.manual_seed(0)
+    torch.save({'state_dict': vn.VOSNet('resnet18').state_dict()}, tmp_path / 'ckpt.pth.tar')
+    base = [sys.executable, 'main.py', 'inference', '-d', str(tmp_path / 'data'), '-r', str(tmp_path / 'ckpt.pth.tar'), '-m',
+            'resnet18', '--ref_num', '5', '--frame_range', '6', '--deterministic', '--encoder-batch', '4']
+    for tag in ('a', 'b'):
+        out = subprocess.run(base + ['-s', str(tmp_path / tag)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+    for vid in ('bear', 'camel'):
+        for i in range(7):
+            assert (tmp_path / 'a' / vid / f'{i:05d}.png').read_bytes() == (tmp_path / 'b' / vid / f'{i:05d}.png').read_bytes()

@@ -213,7 +213,8 @@ def test_config4_thirty_videos_over_eight_shards(tmp_path):
     """configs[3]: the full DAVIS-2017-val layout - 30 videos whose lengths vary 3x - dealt to EIGHT shards by LPT (sharding.py),
     every shard run as its own `main.py inference --shard r 8` process on this box's one GPU (at most four at a time: the box
     allows few processes on its card).  Checks what the 8-GPU run relies on: every video is produced by exactly one shard,
-    complete; no shard's load exceeds the LPT bound; the masks agree with a single-process run over all 30 videos."""
+    complete; no shard's load exceeds the LPT bound; every PNG is byte-identical to a single-process run's over all 30 videos
+    (`--deterministic`, default f16 encoder; reference: videos are independent, src/utils/inference_utils.py:28-48)."""
     from PIL import Image
     sharding = importlib.import_module('semi-supervised-vos_amd.sharding')
     vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
@@ -226,7 +227,7 @@ def test_config4_thirty_videos_over_eight_shards(tmp_path):
     torch.manual_seed(0)
     torch.save({'state_dict': vn.VOSNet('resnet18').state_dict()}, tmp_path / 'ckpt.pth.tar')
     base = [sys.executable, 'main.py', 'inference', '-d', str(tmp_path / 'data'), '-r', str(tmp_path / 'ckpt.pth.tar'), '-m', 'resnet18',
-            '--ref_num', '5', '--frame_range', '6', '--io-workers', '1', '--encoder-dtype', 'f32']
+            '--ref_num', '5', '--frame_range', '6', '--io-workers', '1', '--deterministic']
     one = subprocess.run(base + ['-s', str(tmp_path / 'one')], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     stats = []
@@ -241,13 +242,11 @@ def test_config4_thirty_videos_over_eight_shards(tmp_path):
             stats.append(st)
     assert sum(st['frames'] for st in stats) == sum(lengths) and sum(st['videos'] for st in stats) == 30
     assert [st['frames'] for st in stats] == load
-    # not bit-equal by construction: MIOpen's split-K convolutions accumulate with atomics, so encoder outputs - and on this
-    # random-init / noise dataset a near-tied pixel of the 8x12 map (1 % of a frame each) - can differ from process to process
-    diffs = []
+    n_classes = set()
     for vid, n in names.items():
-        a = np.stack([np.asarray(Image.open(tmp_path / 'one' / vid / f'{i:05d}.png')) for i in range(n)])
-        b = np.stack([np.asarray(Image.open(tmp_path / 'eight' / vid / f'{i:05d}.png')) for i in range(n)])
-        assert a.shape == b.shape and np.array_equal(a[0], b[0])
-        diffs.append(float(np.mean(a != b)))
-        assert diffs[-1] <= 0.03, vid
-    assert float(np.mean(diffs)) <= 0.005, diffs
+        for i in range(n):
+            a = np.asarray(Image.open(tmp_path / 'one' / vid / f'{i:05d}.png'))
+            b = np.asarray(Image.open(tmp_path / 'eight' / vid / f'{i:05d}.png'))
+            assert a.shape == b.shape and np.array_equal(a, b), f'{vid}/{i:05d}.png: {np.mean(a != b) * 100:.3f} % of pixels differ'
+        n_classes.add(len(np.unique(b)))
+    assert max(n_classes) >= 2          # not all collapsed to background

@@ -1,0 +1,129 @@
+"""Which encoder kernels make `main.py inference` differ from run to run / from shard to shard?  
+
+Encodes the SAME padded look-ahead batch several times on the CLI's path (f16, BatchNorm folded, channels_last, fused epilogues)
+and compares the output of EVERY convolution call bitwise:
+  * run vs run in one process                          -> kernels that are not reproducible (atomics / races)
+  * a frame at batch position p vs the same frame at q -> kernels whose result depends on WHERE in the batch a sample sits
+  * eager vs HIP-graph replay
+and prints a digest of the final features, so that two processes can be compared by running the script twice.
+
+    python tools/determinism_probe.py --model resnet18 --size 96 160 --batch 32 --frames 9 [--det] [--pointwise 0|1]
+"""
+import argparse
+import hashlib
+import importlib
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--model', default='resnet18')
+    ap.add_argument('--size', type=int, nargs=2, default=(96, 160))
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--frames', type=int, default=9)
+    ap.add_argument('--dtype', default='f16')
+    ap.add_argument('--det', action='store_true', help='torch.backends.cudnn.deterministic = True (+ VOSPROP_DETERMINISTIC=1)')
+    ap.add_argument('--pointwise', default='1')
+    ap.add_argument('--repeats', type=int, default=3)
+    a = ap.parse_args()
+    os.environ['VOSPROP_POINTWISE'] = a.pointwise
+    if a.det:
+        os.environ['VOSPROP_DETERMINISTIC'] = '1'
+    import numpy as np
+    import torch
+    vn = importlib.import_module('semi-supervised-vos_amd.vos_net')
+    if a.det:
+        torch.backends.cudnn.deterministic = True
+    dt = {'f16': torch.float16, 'bf16': torch.bfloat16, 'f32': None}[a.dtype]
+    torch.manual_seed(0)
+    net = vn.VOSNet(a.model)
+    net.prepare_for_inference(torch.device('cuda', 0), dt)
+    H, W = a.size
+    rs = np.random.RandomState(1)
+    frames = torch.from_numpy(rs.randn(a.frames, 3, H, W).astype(np.float32)).cuda()
+
+    def batch_with(offset):
+        x = torch.zeros((a.batch, 3, H, W), device='cuda')
+        x[offset:offset + a.frames] = frames
+        if dt is not None:
+            x = x.to(dt)
+        return x.contiguous(memory_format=torch.channels_last)
+
+    trace = []
+    orig_nobias, orig_cba = vn._conv_nobias, vn.conv_bias_act
+
+    def tag_of(conv, kind):
+        return f'{kind} {conv.in_channels}->{conv.out_channels} k{conv.kernel_size[0]} s{conv.stride[0]}'
+
+    def nobias(x, conv):
+        y = orig_nobias(x, conv)
+        trace.append((tag_of(conv, 'miopen'), y.detach().clone()))
+        return y
+
+    def cba(x, conv, bias, residual=None, relu=True):
+        n0 = len(trace)
+        y = orig_cba(x, conv, bias, residual, relu)
+        kind = 'gemm' if len(trace) == n0 else 'conv+epi'
+        trace.append((tag_of(conv, kind) + (' +res' if residual is not None else ''), y.detach().clone()))
+        return y
+
+    vn._conv_nobias, vn.conv_bias_act = nobias, cba
+
+    def run(offset):
+        trace.clear()
+        with torch.no_grad():
+            f = net(batch_with(offset))
+        torch.cuda.synchronize()
+        return [(t, y) for t, y in trace], f.detach().clone()
+
+    def sl(y, offset):
+        return y[offset:offset + a.frames]
+
+    print(f'# {a.model} {a.dtype} {H}x{W} batch {a.batch} ({a.frames} real frames) det={a.det} pointwise={a.pointwise}')
+    run(0)                                   # warm (MIOpen look-ups, GEMM plans)
+    base, f0 = run(0)
+    bad_run = {}
+    for r in range(a.repeats):
+        tr, f = run(0)
+        for i, ((t, y0), (_, y1)) in enumerate(zip(base, tr)):
+            if not torch.equal(y0, y1):
+                d = (y0.float() - y1.float()).abs()
+                bad_run.setdefault((i, t), []).append((float(d.max()), float((d > 0).float().mean())))
+    print(f'run-to-run, {a.repeats} repeats, {len(base)} convolution calls: {len(bad_run)} NOT bit-reproducible')
+    for (i, t), v in sorted(bad_run.items()):
+        print(f'   call {i:3d} {t:40s} max |diff| {max(x[0] for x in v):.3e}  differing {max(x[1] for x in v) * 100:.3f} %  in {len(v)}/{a.repeats} repeats')
+    # position dependence: same frames at batch offset 0 and at offset `frames` (what a frame sees in a 1-process vs a sharded run)
+    off = min(a.frames, a.batch - a.frames)
+    first_bad = None
+    if off > 0:
+        tr, f1 = run(off)
+        n_bad = 0
+        for i, ((t, y0), (_, y1)) in enumerate(zip(base, tr)):
+            if not torch.equal(sl(y0, 0), sl(y1, off)):
+                n_bad += 1
+                if (i, t) not in bad_run and first_bad is None:
+                    first_bad = (i, t)
+        print(f'batch position 0 vs {off}: {n_bad} calls differ; first one that is run-to-run clean: {first_bad}')
+        print(f'   final features equal across positions: {torch.equal(sl(f0, 0), sl(f1, off))}')
+    vn._conv_nobias, vn.conv_bias_act = orig_nobias, orig_cba
+    # graph replay vs eager
+    g = vn.GraphedEncoder(net)
+    x = batch_with(0)
+    with torch.no_grad():
+        y_g = g(x).clone()
+        y_g2 = g(x).clone()
+        y_e = net(x)
+    torch.cuda.synchronize()
+    print(f'graph replay == eager: {torch.equal(y_g, y_e)}; replay == replay: {torch.equal(y_g, y_g2)}; graphed: {not g.failed}')
+    dig = hashlib.sha1(sl(f0, 0).float().cpu().numpy().tobytes()).hexdigest()[:16]
+    dig_g = hashlib.sha1(sl(y_g, 0).float().cpu().numpy().tobytes()).hexdigest()[:16]
+    print(f'digest(final features, eager) {dig}   digest(graph) {dig_g}   pid {os.getpid()}')
+
+
+if __name__ == '__main__':
+    main()
