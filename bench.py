@@ -63,6 +63,17 @@ def synthetic_clip(H, W, n_frames, seed, device):
     return clip, ann
 
 
+def kernel_source_hash():
+    """sha1 (12 hex digits) over the propagation-kernel sources: ties a committed PMC profile to the code it measured."""
+    import hashlib
+    h = hashlib.sha1()
+    src = ROOT / 'semi-supervised-vos_amd' / 'csrc'
+    for name in sorted(p.name for p in src.glob('prop_*.h')) + ['common.h', 'aux_kernels.h']:
+        h.update(name.encode())
+        h.update((src / name).read_bytes())
+    return h.hexdigest()[:12]
+
+
 def cpu_model_name():
     try:
         for line in open('/proc/cpuinfo'):
@@ -154,6 +165,7 @@ def end_to_end_leg(args, wl, dev, clip, pool, net, eng, enc_dtype, fence, world,
     frames_host.copy_(u8)
     del u8
     masks_host = torch.empty((K, H, W), dtype=torch.uint8).pin_memory()
+    masks_host.fill_(255)          # no class is 255: a mask that never landed shows
     bufs = [torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
     copied = [torch.cuda.Event(), torch.cuda.Event()]
     consumed = [torch.cuda.Event(), torch.cuda.Event()]
@@ -205,16 +217,26 @@ def end_to_end_leg(args, wl, dev, clip, pool, net, eng, enc_dtype, fence, world,
         download(k, n)
     fence()
     dt = time.perf_counter() - t0
+    # every mask is on the host (no 255 left), the last batch equals what the device holds, and the labels did not collapse
+    last_k = n_batches - 1
+    n_last = min(B, K - last_k * B)
+    landed = not bool((masks_host == 255).any())
+    same = bool(torch.equal(masks_host[last_k * B:last_k * B + n_last], mask_dev[last_k % 2][:n_last].cpu()))
+    if not (landed and same):
+        raise SystemExit(f'end_to_end: masks missing on the host (all landed: {landed}, last batch equal to the device copy: {same})')
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device='cpu' if on_gloo else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    hist = torch.bincount(masks_host.reshape(-1).to(torch.int64), minlength=4)
     return {'value': world * K / dt, 'unit': 'frames/s', 'steps': K, 'ms_per_step': dt / K * 1e3,
             'bytes_over_pcie_per_frame': H * W * 3 + H * W,
             'what': 'uint8 HWC frames in pinned host memory -> H2D (copy stream, one batch ahead) -> ToTensor + Normalize on the '
                     'device -> encoder -> propagation -> mask -> D2H into pinned host memory (one copy per batch and direction, copy stream); clock stops with the last mask on the host',
-            'mask_checksum': int(masks_host[-1].to(torch.int64).sum())}
+            'masks_checked': 'all K masks landed (buffer pre-filled with 255), last batch equals the device copy',
+            'mask_checksum': int(masks_host.to(torch.int64).sum()), 'mask_nonzero_pixels': int((masks_host != 0).sum()),
+            'mask_class_histogram': [int(v) for v in hist]}
 
 
 def free_port():
@@ -285,7 +307,8 @@ def main():
     ap.add_argument('--steps', type=int, default=384)
     ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--workload', default='davis480p_r50_dense', choices=sorted(WORKLOADS) + ['stub_cpu'])
-    ap.add_argument('--encoder-dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--encoder-dtype', default='f16', choices=['bf16', 'f16', 'f32'],
+                    help='encoder precision; f16 = the reference (torch.cuda.amp.autocast, src/utils/inference_utils.py:35,52)')
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help='barrier / max-reduce transport for N > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -302,8 +325,9 @@ def main():
         # no launcher around us: become one.  Nothing in this process has touched a GPU yet (importing torch does not).
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     # the dispatch-attached event pairs that time the propagation kernel inside the loop cost ~1.7 us per launch they ride on:
-    # every 4th launch of the timed region carries them (96 of the default 384; `roofline.kernel_launches_timed` says how many)
-    os.environ.setdefault('VOSPROP_TIMING_STRIDE', '4')
+    # in a long run every 4th launch of the timed region carries them (96 of the default 384), in a short one (<= 64 steps, the
+    # driver's 20) EVERY launch does; `roofline.kernel_launches_timed` says how many
+    os.environ.setdefault('VOSPROP_TIMING_STRIDE', '1' if args.steps <= 64 else '4')
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -338,7 +362,10 @@ def main():
     torch.manual_seed(0)
     net = vos_net.VOSNet(wl['model'])
     model_state = {k: v.clone() for k, v in net.state_dict().items()}
-    net.prepare_for_inference(dev, enc_dtype, miopen_find=not args.no_miopen_find)
+    # the features leave the encoder as channels-last bf16 (one conversion pass over the batch inside the captured graph): the
+    # propagation kernel then reads the target frame in place and combine_kernel carries the ring copy - what the CLI does
+    net.prepare_for_inference(dev, enc_dtype, miopen_find=not args.no_miopen_find,
+                              feature_dtype=torch.bfloat16 if enc_dtype != torch.float32 else None)
     if not args.no_encoder_graph:
         net = vos_net.GraphedEncoder(net, max_graphs=8)     # the look-ahead batch forward as one HIP graph launch per shape
 
@@ -367,13 +394,20 @@ def main():
         feat_buf['pos'] += 1
         return f
 
+    # first output row / column whose ATen nearest source index is i / j: the mask read there IS the low-resolution class map
+    up_r = [next(y for y in range(H) if min(int(np.floor(np.float32(y) * (np.float32(Hd) / np.float32(H)))), Hd - 1) == i) for i in range(Hd)]
+    up_c = [next(x for x in range(W) if min(int(np.floor(np.float32(x) * (np.float32(Wd) / np.float32(W)))), Wd - 1) == j) for j in range(Wd)]
+
     def one_frame(i, keep=False, end=1 << 60):
+        # every step - kept or timed - runs the SAME kernel form: mask only (pred_out_dev == NULL: no softmax denominators), the
+        # target frame read in place; `mask_parity` therefore checks the form that is timed
         feats = encode_next(i, end)[None]
-        pred, mask = eng.step(feats, want_pred=keep, want_mask=True)
+        _, mask = eng.step(feats, want_pred=False, want_mask=True)
         if keep:
             keep_feats.append(feats.float().cpu())
-            keep_cls.append(None if pred is None else pred.argmax(0).cpu())
-            keep_masks.append(None if mask is None else mask.cpu().numpy())
+            m = None if mask is None else mask.cpu().numpy()
+            keep_cls.append(None if m is None else torch.from_numpy(np.ascontiguousarray(m[np.ix_(up_r, up_c)])).reshape(-1).long())
+            keep_masks.append(m)
         return mask
 
     fi = 0
@@ -455,18 +489,23 @@ def main():
 
     # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process (rocprofv3 collects them, in
     # their own passes), so the line carries the committed measurement for this workload (tools/traffic_pmc.sh) or null
+    # A profile is only quoted while it describes the kernels that ran: it carries the hash of the kernel sources it was taken
+    # with (kernel_source_hash below); after any edit of csrc/prop_*.h / common.h the line says traffic: null until the profile is
+    # re-taken.
     traffic, traffic_src, pmc = None, None, {}
     prof = Path(__file__).resolve().parent / 'profiles'
-    for tj in (prof / f'r02_prop_kernel_traffic_{args.workload}.json',
-               prof / 'r01_prop_kernel_traffic.json' if args.workload == 'davis480p_r50_dense' else None):
-        if tj is None or not tj.exists():
-            continue
+    src_hash = kernel_source_hash()
+    tj = prof / f'r03_prop_kernel_traffic_{args.workload}.json'
+    if tj.exists():
         try:
             t = json.loads(tj.read_text())
-            traffic = float(t['traffic_bytes_per_launch'])
-            traffic_src = f'profiles/{tj.name}: ' + t['how']
-            pmc = {k: t[k] for k in ('mfma_busy_frac', 'l2_hit_rate', 'hbm_gb_per_s', 'counters_source') if k in t}
-            break
+            if t.get('kernel_source_hash') == src_hash:
+                traffic = float(t['traffic_bytes_per_launch'])
+                traffic_src = f'profiles/{tj.name}: ' + t['how']
+                pmc = {k: t[k] for k in ('mfma_busy_frac', 'l2_hit_rate', 'hbm_gb_per_s', 'counters_source') if k in t}
+            else:
+                traffic_src = (f'profiles/{tj.name} was taken with kernel sources {t.get("kernel_source_hash")}, this build is '
+                               f'{src_hash}: not quoted')
         except Exception:
             traffic = None
     if rank == 0:
@@ -477,7 +516,11 @@ def main():
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'image': [H, W], 'feature_map': [Hd, Wd], 'ref_num': wl['ref_num'],
                        'frame_range': cfg['frame_range'], 'topk': wl['topk'], 'encoder': wl['model'],
-                       'encoder_dtype': args.encoder_dtype, 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
+                       'encoder_dtype': args.encoder_dtype,
+                       'feature_handoff': ('channels-last bf16 from the encoder graph, target frame read in place, ring copy inside '
+                                           'combine_kernel' if enc_dtype != torch.float32 and not wl['topk'] and not wl.get('materialise')
+                                           else 'push kernel into the ring per frame'),
+                       'step_form': 'mask only (pred_out_dev = NULL)', 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
             'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us, 'end_to_end': end_to_end,
             'roofline': {'kernel': ('prop_dense_kernel<.,.,1> + <.,.,2> (affinity out to HBM, then back)' if hbm_bound else
@@ -487,7 +530,8 @@ def main():
                          'frac': achieved_gbs / HBM_PEAK_GBS if hbm_bound else achieved / MFMA_BF16_PEAK_TFLOPS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel_us': prop_us,
                          'kernel_launches_timed': timed_launches, 'kernel_us_back_to_back': b2b_us, 'flops_per_launch': st['flops'],
-                         'algorithmic_bytes_per_launch': st['bytes'], 'workgroups': st['workgroups'], 'pmc': pmc},
+                         'algorithmic_bytes_per_launch': st['bytes'], 'workgroups': st['workgroups'], 'pmc': pmc,
+                         'kernel_source_hash': src_hash},
         }
         if world == 1 and not args.no_cpu_baseline:
             T0 = len(keep_feats)

@@ -282,120 +282,21 @@ __device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t*
     if (lab_lo && prob) *(bf16x8*)(lab_lo + off) = ol;
 }
 
-// Top-k, between the passes: per target pixel merge the sorted group-maximum lists of all partial slots (2 half-wave
-// lists per slot) and take the k-th largest value = lower bound of the k-th largest weighted exponent; also the exact
-// column max of the raw scores; zero the candidate counter.  grid = ceil(HWp/64), block = 256 (64 pixels x 4 lanes).
-// [r2] The round-1 form walked every list with one DEPENDENT global load per entry (load, compare, break or insert: ~100 round trips
-// per pixel, 60 us for 26 blocks).  Now a partial slot's two lists are fetched whole (2 x KS independent loads in flight, the next
-// slot id with them), the merged list has KS = ceil(k/8)*8 slots like pass 1's, an insertion is one v_med3 per slot, and four lanes
-// share a pixel's slots (merged through LDS).
-template <int KS>
-__device__ __forceinline__ void topk_select_body(const float* __restrict__ part, const int* __restrict__ plist, int u0, int u1,
-                                                 int tcol, int g, float (&lst)[KS], float& M) {
-    const size_t ustride = (size_t)(1 + 2 * kTopkMax) * kBT;
-#pragma unroll
-    for (int i = 0; i < KS; ++i) lst[i] = -3.0e38f;
-    M = -3.0e38f;
-    for (int u = u0 + g; u < u1; u += 4) {       // this lane's quarter of the partial slots (slots of a target tile are consecutive,
-                                                 // engine.hip get_plan: the slot list is the identity and is not read)
-        const float* pu = part + (size_t)u * ustride + tcol;
-        float v[2][KS];
-        const float m = pu[0];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int i = 0; i < KS; ++i) v[hh][i] = pu[(size_t)(1 + hh * kTopkMax + i) * kBT];
-        M = fmaxf(M, m);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-            for (int i = 0; i < KS; ++i) {
-                const float x = v[hh][i];
-                if (x <= lst[KS - 1]) break;   // both lists are descending
-#pragma unroll
-                for (int q = KS - 1; q >= 1; --q) lst[q] = __builtin_amdgcn_fmed3f(lst[q - 1], lst[q], x);
-                lst[0] = fmaxf(lst[0], x);
-            }
-        }
-    }
-}
-
-// block = 256 = 64 target pixels x 4 lanes: every lane merges a quarter of the pixel's partial slots, lane 0 merges the four lists
-template <int KS>
-__device__ __forceinline__ void topk_select_pixel(const float* __restrict__ part, const int* __restrict__ plist_off,
-                                                  const int* __restrict__ plist, int k, int t, bool live, int col, int g,
-                                                  float (*lsts)[kTopkMax][64], float (*mred)[64], float* __restrict__ thr,
-                                                  float* __restrict__ mfin) {
-    float lst[KS], M = -3.0e38f;
-#pragma unroll
-    for (int i = 0; i < KS; ++i) lst[i] = -3.0e38f;
-    if (live) {
-        const int tt = t / kBT, tcol = t % kBT;
-        topk_select_body<KS>(part, plist, plist_off[tt], plist_off[tt + 1], tcol, g, lst, M);
-    }
-    mred[g][col] = M;
-    if (g > 0) {
-#pragma unroll
-        for (int i = 0; i < KS; ++i) lsts[g - 1][i][col] = lst[i];
-    }
-    __syncthreads();
-    if (g == 0 && live) {
-        for (int gg = 0; gg < 3; ++gg)
-            for (int i = 0; i < KS; ++i) {
-                const float x = lsts[gg][i][col];
-                if (x <= lst[KS - 1]) break;
-#pragma unroll
-                for (int q = KS - 1; q >= 1; --q) lst[q] = __builtin_amdgcn_fmed3f(lst[q - 1], lst[q], x);
-                lst[0] = fmaxf(lst[0], x);
-            }
-        float vk = lst[0];
-#pragma unroll
-        for (int q = 1; q < KS; ++q)
-            if (q < k) vk = lst[q];
-        thr[t] = vk;
-        mfin[t] = fmaxf(fmaxf(mred[0][col], mred[1][col]), fmaxf(mred[2][col], mred[3][col]));
-    }
-}
-
-__global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ part, const int* __restrict__ plist_off,
-                                                          const int* __restrict__ plist, int k, int HW, int HWp,
-                                                          float* __restrict__ thr, float* __restrict__ mfin,
-                                                          unsigned* __restrict__ cnt) {
-    __shared__ float lsts[3][kTopkMax][64];
-    __shared__ float mred[4][64];
-    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + col;
-    if (g == 0 && t < HWp) {
-        cnt[t] = 0;
-        if (t >= HW) { thr[t] = 3.0e38f; mfin[t] = 0.0f; }
-    }
-    const bool live = t < HW;
-    if (k <= 8) topk_select_pixel<8>(part, plist_off, plist, k, t, live, col, g, lsts, mred, thr, mfin);
-    else if (k <= 16) topk_select_pixel<16>(part, plist_off, plist, k, t, live, col, g, lsts, mred, thr, mfin);
-    else if (k <= 24) topk_select_pixel<24>(part, plist_off, plist, k, t, live, col, g, lsts, mred, thr, mfin);
-    else topk_select_pixel<kTopkMax>(part, plist_off, plist, k, t, live, col, g, lsts, mred, thr, mfin);
-}
-
-struct TopkCombineArgs {
-    const float* part;       // pass-2 partials: rows (m, l)
-    const int* plist_off;
-    const int* plist;
-    const float* thr;
-    const float* mfin;
-    const unsigned* cnt;
-    const uint2* cand;
-    const uint8_t* cls_ring; // [cap][HWp] class index of every reference pixel
-    int slot[kMaxRef];
-    int k, d, HW, HWp;
-    float c;
-};
-
-// Top-k, after pass 2: denominators from the partials, the k largest candidates of each target pixel summed per class.
-// grid = ceil(HW/64), block = 256 = 64 target pixels x 4 lanes; all 256 then pack the block's label tiles.
-// [r2] Round 1 gave a pixel ONE thread: ~10 dependent partial loads, then a load per candidate, then a gather per kept candidate
-// (36 us).  Now the four lanes of a pixel take every fourth partial / candidate with their loads in flight four at a time, keep
-// private sorted lists (one v_med3 per slot), and lane 0 merges the four lists and the four per-class sums through LDS in a fixed
-// order.
+// ---------------------------------------------------------------------------------------------------------------
+// Top-k variant (NOT in the reference): per target pixel keep the k largest entries of the weighted
+// affinity A[.,t] = P[.,t] w[.,t], zero the rest, no renormalisation (k >= N*HW reproduces the dense result).  Ranking by A is
+// ranking by the exponent E = S c + log2 w (the softmax max and denominator are column constants).  [r3] Two passes on the dense
+// kernel's pipeline (prop_dense.h TK = 1 / 2) with these two kernels between and after them:
+//   pass 1   per lane the KS = ceil(k/8)*8 largest GROUP maxima (group = the 16 rows of a reference tile a lane owns), each packed
+//            with its (stream index r, half h) in the low `bits` mantissa bits;
+//   select2  merges a column's lists: v_k = its k-th largest packed maximum.  With D = |v_k| 2^(bits-22) >= the packing error:
+//            the true k-th largest group maximum G_k >= v_k - D, every element of the true top-k is >= G_k (k groups have a
+//            maximum >= G_k, each holds an element >= G_k) and lives in a group whose packed maximum is >= v_k - 2D.  So
+//            thr_elem = v_k - D bounds the elements, thr_grp = v_k - 2D the groups, and the tiles of the groups that reach
+//            thr_grp - at most ~k per column - are marked in the target tile's bitmap;
+//   pass 2   re-scores the marked tiles only and dumps, per lane, the 16 exponents of every group that reaches thr_grp;
+//   combine2 takes the k largest dumped exponents of a column exactly, sums 2^E per class, arg-maxes, packs the new labels.
+// No atomics on values, no counters shared between lanes, no second full scoring pass.
 template <int KS>
 __device__ __forceinline__ void topk_list_insert(float (&lst)[KS], float x) {
 #pragma unroll
@@ -403,13 +304,110 @@ __device__ __forceinline__ void topk_list_insert(float (&lst)[KS], float x) {
     lst[0] = fmaxf(lst[0], x);
 }
 
-__global__ __launch_bounds__(256) void topk_combine_kernel(const TopkCombineArgs a, float* __restrict__ pred,
-                                                           uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi,
-                                                           bf16_t* __restrict__ lab_lo) {
+struct TopkSelectArgs {
+    const float* part;        // pass-1 lists: [slot][2 * KS][kBT]
+    const int* plist_off;     // slots of target tile tt: plist_off[tt] .. plist_off[tt + 1] - 1 (consecutive, engine.hip get_plan)
+    int k, HW, bits, words;   // bits: index bits of a packed maximum; words: bitmap words per target tile
+    float c;
+    float* thr_grp;           // [TT*256]
+    float* thr_elem;          // [TT*256]
+    unsigned* bitmap;         // [TT][words], cleared by pass 1
+};
+
+// grid = TT * 4, block = 256 = 64 target pixels x 4 lanes (a block's pixels belong to ONE target tile: 256 = 4 x 64)
+template <int KS>
+__global__ __launch_bounds__(256) void topk_select2_kernel(const TopkSelectArgs a) {
+    __shared__ float lsts[3][KS][64];
+    __shared__ unsigned bm[2048];      // this block's marks (words <= 2048: NT <= 65 536, checked on the host)
+    const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
+    const int t = blockIdx.x * 64 + col;
+    const int tt = (blockIdx.x * 64) / kBT, tcol = (blockIdx.x * 64) % kBT + col;
+    for (int i = tid; i < a.words; i += 256) bm[i] = 0u;
+    const bool live = t < a.HW;
+    float lst[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) lst[i] = kTkDummy;
+    if (live) {
+        const int u0 = a.plist_off[tt], u1 = a.plist_off[tt + 1];
+        const size_t ustride = (size_t)(2 * KS) * kBT;
+        for (int u = u0 + g; u < u1; u += 4) {      // this lane's quarter of the slots; a slot's two lists fetched whole
+            const float* pu = a.part + (size_t)u * ustride + tcol;
+            float v[2][KS];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int i = 0; i < KS; ++i) v[hh][i] = pu[(size_t)(hh * KS + i) * kBT];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int i = 0; i < KS; ++i) {
+                    if (v[hh][i] <= lst[KS - 1]) break;      // both lists are descending
+                    topk_list_insert<KS>(lst, v[hh][i]);
+                }
+            }
+        }
+    }
+    if (g > 0) {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) lsts[g - 1][i][col] = lst[i];
+    }
+    __syncthreads();
+    if (g == 0) {
+        float tg = 3.0e38f, te = 3.0e38f;      // dead columns: nothing reaches the threshold
+        if (live) {
+            for (int gg = 0; gg < 3; ++gg)
+                for (int i = 0; i < KS; ++i) {
+                    const float x = lsts[gg][i][col];
+                    if (x <= lst[KS - 1]) break;
+                    topk_list_insert<KS>(lst, x);
+                }
+            float vk = lst[0];
+#pragma unroll
+            for (int q = 1; q < KS; ++q)
+                if (q < a.k) vk = lst[q];
+            const float D = fmaxf(fabsf(vk), 1.0e-30f) * __builtin_amdgcn_exp2f((float)(a.bits - 22));
+            te = vk - D;
+            tg = vk - 2.0f * D;
+            const unsigned imask = (1u << a.bits) - 1u;
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                if (lst[q] >= tg && lst[q] > -1.0e37f) {      // (not a "no group" filler)
+                    const unsigned r = (__float_as_uint(lst[q]) & imask) >> 1;
+                    atomicOr(&bm[r >> 5], 1u << (r & 31));
+                }
+            }
+        }
+        a.thr_grp[t] = tg;
+        a.thr_elem[t] = te;
+    }
+    __syncthreads();
+    unsigned* gb = a.bitmap + (size_t)tt * a.words;
+    for (int i = tid; i < a.words; i += 256)
+        if (bm[i]) atomicOr(&gb[i], bm[i]);
+}
+
+struct TopkCombineArgs {
+    const float* thr_elem;    // [TT*256]
+    const float* dump;        // [TT*256][2][chunks][cap][16]
+    const unsigned* dump_r;   // [TT*256][2][chunks][cap]
+    const unsigned* cnt;      // [TT*256][2][chunks]
+    const uint8_t* cls_ring;  // [ring slots][HWp] class index of every reference pixel
+    const float* norm_part;   // dense partials (m, l, ...) of the same step when the PREDICTION is wanted, else nullptr: the result
+    const int* plist_off;     //   is then the un-normalised sum (its arg-max is the same)
+    int norm_rows;            // rows of one dense partial slot (2 + d)
+    int slot[kMaxRef];
+    int k, d, HW, HWp, n_ref, chunks, cap;
+    float c;
+};
+
+// grid = ceil(HW/64), block = 256 = 64 target pixels x 4 lanes; all 256 then pack the block's label tiles.
+__global__ __launch_bounds__(256) void topk_combine2_kernel(const TopkCombineArgs a, float* __restrict__ pred,
+                                                            uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi,
+                                                            bf16_t* __restrict__ lab_lo) {
     __shared__ float outv[kMaxClasses][64];
     __shared__ float outg[3][kMaxClasses][64];      // per-class sums of lanes 1..3 of a pixel
     __shared__ float lsts[3][kTopkMax][64];         // sorted candidate lists of lanes 1..3
-    __shared__ float lred[4][64];                   // denominator parts, then [0] = tau
+    __shared__ float red[2][64];                    // [0] = tau, [1] = reference exponent
     __shared__ uint8_t clsv[64];
     const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
     const int t = blockIdx.x * 64 + col;
@@ -417,41 +415,37 @@ __global__ __launch_bounds__(256) void topk_combine_kernel(const TopkCombineArgs
     if (g == 0) {
         for (int k = 0; k < a.d; ++k) outv[k][col] = 0.0f;
         clsv[col] = 0;
+    } else {
+        for (int k = 0; k < a.d; ++k) outg[g - 1][k][col] = 0.0f;
     }
-    unsigned n = 0;
-    const uint2* cd = a.cand + (size_t)(live ? t : 0) * kTopkCap;
     float lst[kTopkMax];
 #pragma unroll
-    for (int i = 0; i < kTopkMax; ++i) lst[i] = -3.0e38f;
-    float L = 0.0f;
+    for (int i = 0; i < kTopkMax; ++i) lst[i] = kTkDummy;
+    const float floor_e = -1.0e29f * a.c;      // masked rows (S = -1e30) sit below this
+    const float te = live ? fmaxf(a.thr_elem[t], floor_e) : 3.0e38f;
+    const int n_units = 2 * a.chunks;          // (half, share) pairs of this pixel
+    // phase 1: the k largest exponents among the dumped groups (this lane: every 4th group)
     if (live) {
-        const int tt = t / kBT, tcol = t % kBT;
-        const int u0 = a.plist_off[tt], u1 = a.plist_off[tt + 1];
-        n = a.cnt[t];
-        if (n > (unsigned)kTopkCap) n = kTopkCap;
-        // this lane's quarter of the denominators: slot ids first, then the values, all in flight together
-        int sl[4];
+        int gi = 0;
+        for (int u = 0; u < n_units; ++u) {
+            const size_t ub = (size_t)t * n_units + u;
+            unsigned n = a.cnt[ub];
+            if (n > (unsigned)a.cap) n = a.cap;
+            for (unsigned q = 0; q < n; ++q, ++gi) {
+                if ((gi & 3) != g) continue;
+                const f32x4* e4 = (const f32x4*)(a.dump + (ub * a.cap + q) * 16);
+                const f32x4 v0 = e4[0], v1 = e4[1], v2 = e4[2], v3 = e4[3];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sl[q] = u0 + g + 4 * q < u1 ? u0 + g + 4 * q : -1;     // (identity slot list)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (sl[q] >= 0) L += a.part[((size_t)sl[q] * 2 + 1) * kBT + tcol];
-        for (int u = u0 + g + 16; u < u1; u += 4) L += a.part[((size_t)u * 2 + 1) * kBT + tcol];
-        // this lane's quarter of the candidates, four loads in flight
-        for (unsigned i = g; i < n; i += 16) {
-            float x[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = i + 4 * q < n ? __uint_as_float(cd[i + 4 * q].x) : -3.0e38f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (x[q] > lst[kTopkMax - 1]) topk_list_insert<kTopkMax>(lst, x[q]);
+                for (int e = 0; e < 16; ++e) {
+                    const float x = e < 4 ? v0[e & 3] : e < 8 ? v1[e & 3] : e < 12 ? v2[e & 3] : v3[e & 3];
+                    if (x >= te && x > lst[kTopkMax - 1]) topk_list_insert<kTopkMax>(lst, x);
+                }
+            }
         }
     }
-    lred[g][col] = L;
     if (g > 0) {
 #pragma unroll
         for (int i = 0; i < kTopkMax; ++i) lsts[g - 1][i][col] = lst[i];
-        for (int k = 0; k < a.d; ++k) outg[g - 1][k][col] = 0.0f;
     }
     __syncthreads();
     if (g == 0 && live) {
@@ -465,22 +459,51 @@ __global__ __launch_bounds__(256) void topk_combine_kernel(const TopkCombineArgs
 #pragma unroll
         for (int q = 1; q < kTopkMax; ++q)
             if (q < a.k) tau = lst[q];
-        const float Lt = ((lred[0][col] + lred[1][col]) + lred[2][col]) + lred[3][col];
-        lred[0][col] = tau;
-        lred[1][col] = 1.0f / Lt;
+        red[0][col] = fmaxf(tau, te);      // fewer than k real elements: everything real is kept
+        red[1][col] = lst[0];              // reference exponent of the un-normalised sum: the largest one
     }
     __syncthreads();
+    // phase 2: the kept elements, summed per class
     if (live) {
-        const float tau = lred[0][col], inv = lred[1][col];
-        const float mc = a.mfin[t] * a.c;
+        const float tau = red[0][col];
+        float eref = red[1][col], inv = 1.0f;
+        if (a.norm_part) {      // the prediction is wanted: the softmax max and denominator of the column, from the dense partials
+            const int tt = t / kBT, tcol = t % kBT;
+            const int u0 = a.plist_off[tt], u1 = a.plist_off[tt + 1];
+            float M = -3.0e38f, L = 0.0f;
+            for (int u = u0; u < u1; ++u) {
+                const float* pu = a.norm_part + (size_t)u * a.norm_rows * kBT + tcol;
+                const float m = pu[0], Mn = fmaxf(M, m);
+                L = L * __builtin_amdgcn_exp2f((M - Mn) * a.c) + pu[kBT] * __builtin_amdgcn_exp2f((m - Mn) * a.c);
+                M = Mn;
+            }
+            eref = M * a.c;
+            inv = 1.0f / L;
+        }
         float (*acc)[64] = g == 0 ? outv : outg[g - 1];
-        for (unsigned i = g; i < n; i += 4) {
-            const uint2 e = cd[i];
-            const float E = __uint_as_float(e.x);
-            if (E < tau) continue;
-            const unsigned fn = e.y / (unsigned)a.HWp, px = e.y - fn * (unsigned)a.HWp;
-            const int kcls = a.cls_ring[(size_t)a.slot[fn] * a.HWp + px];
-            if (kcls < a.d) acc[kcls][col] += __builtin_amdgcn_exp2f(E - mc) * inv;
+        int gi = 0;
+        for (int u = 0; u < n_units; ++u) {
+            const size_t ub = (size_t)t * n_units + u;
+            const int hh = u / a.chunks;
+            unsigned n = a.cnt[ub];
+            if (n > (unsigned)a.cap) n = a.cap;
+            for (unsigned q = 0; q < n; ++q, ++gi) {
+                if ((gi & 3) != g) continue;
+                const f32x4* e4 = (const f32x4*)(a.dump + (ub * a.cap + q) * 16);
+                const f32x4 v0 = e4[0], v1 = e4[1], v2 = e4[2], v3 = e4[3];
+                const unsigned r = a.dump_r[ub * a.cap + q];
+                const unsigned pt = r / (unsigned)a.n_ref, fn = r - pt * (unsigned)a.n_ref;
+                if (pt >= (unsigned)(a.HWp / kTileR)) continue;      // (the "no group" filler of a segment's first step)
+                const uint8_t* cr = a.cls_ring + (size_t)a.slot[fn] * a.HWp + pt * kTileR;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float x = e < 4 ? v0[e & 3] : e < 8 ? v1[e & 3] : e < 12 ? v2[e & 3] : v3[e & 3];
+                    if (x >= tau && x > floor_e) {
+                        const int kcls = cr[acc_row(e, hh)];
+                        if (kcls < a.d) acc[kcls][col] += __builtin_amdgcn_exp2f(x - eref) * inv;
+                    }
+                }
+            }
         }
     }
     __syncthreads();

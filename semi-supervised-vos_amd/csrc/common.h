@@ -16,8 +16,9 @@ constexpr int kMaxRef = 64;
 constexpr int kCoordCh = 16;       // extra K channels that carry the spatial prior
 constexpr int kContinuousFrame = 4;   // reference src/config.py:13
 constexpr int kTopkMax = 32;       // largest k of the top-k variant (list length kept per lane in pass 1)
-constexpr int kTopkCap = 16 * kTopkMax;   // candidates per target pixel that can exceed the pass-1 bound (see prop_bf16.h)
 constexpr int kXcd = 8;            // XCDs: blocks b and b+8 share an L2 (placement is a speed matter only)
+constexpr int kTkListCap = 1024;   // top-k pass 2: marked reference tiles one workgroup walks at most (its share of a target tile's)
+constexpr float kTkDummy = -3.0e38f;   // "no group": below every real weighted exponent (masked rows sit at -1e30 c)
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -89,12 +90,19 @@ struct PropArgs {
     double g1, g2;              // 1 / (sigma^2 * temperature) for sigma1, sigma2
     double two_over_w, gamma;   // 2/W_d, 1 + 1/W_d^2
     int part_rows;              // rows of one partial slot: 2 + d (dense), 1 + 2*kTopkMax (top-k pass 1), 2 (top-k pass 2)
-    // top-k variant (two passes, see prop_bf16.h)
-    int tk_k;                   // k of the top-k variant (pass 1 maintains ceil(k / 8) * 8 list slots)
-    const float* tk_thr;        // [HWp] pass 2: lower bound of the k-th largest weighted exponent of each target pixel
-    const float* tk_m;          // [HWp] pass 2: column max of the raw scores (exact softmax max, from pass 1)
-    unsigned* tk_cnt;           // [HWp] pass 2: number of candidates appended per target pixel
-    uint2* tk_cand;             // [HWp][kTopkCap] pass 2: (exponent bits, reference row id = n*HWp + p)
+    // top-k variant (two passes on the dense kernel's pipeline, prop_dense.h TK = 1 / 2)
+    int tk_k;                   // k of the top-k variant (pass 1 keeps KS = ceil(k / 8) * 8 list slots per lane)
+    const float* tk_thr;        // [TT*256] pass 2: a group whose packed maximum reaches this holds candidates of the target pixel
+    // [r3] top-k on the dense kernel's pipeline (prop_dense.h TK = 1 / 2, aux_kernels.h topk_select2 / topk_combine2)
+    int tk_idx_bits;            // low mantissa bits of a packed group maximum that hold (stream index << 1 | half)
+    unsigned* tk_bitmap;        // [TT][tk_words] one bit per reference tile (stream index): some column of the target tile has a
+    int tk_words;               //   candidate group there; cleared by pass 1, marked by topk_select2_kernel, walked by pass 2
+    int tk_bitmap_words;        // TT * tk_words
+    int tk_chunks;              // pass 2: workgroups that share one target tile's marked tiles
+    int tk_cap;                 // pass 2: groups one lane can dump per share
+    float* tk_dump;             // [TT*256][2][tk_chunks][tk_cap][16] weighted exponents of the dumped groups
+    unsigned* tk_dump_r;        // [TT*256][2][tk_chunks][tk_cap]     their stream indices
+    unsigned* tk_cnt;           // [TT*256][2][tk_chunks]             groups dumped
     int no_skew;                // dense kernel: 1 = both waves of a SIMD keep their barrier at the step end (VOSPROP_DENSE_SKEW=0, A/B only)
     unsigned long long* dbg;    // diagnostic builds only (-DVOSPROP_STAMP): per-wave cycle sums; else nullptr
 };

@@ -43,9 +43,14 @@ struct LastProp {
     bool materialise = false;
     bool no_l = false;    // dense label mode, prediction not requested: prop_dense_kernel<..., NEED_L = false>
     int topk = 0;
-    int rows_pass1 = 0;
-    const int* d_off = nullptr;    // plan lists (top-k select between the passes)
-    const int* d_list = nullptr;
+    // top-k (prop_dense.h TK 1 / 2): pass 1 = `args` with the list partials, then topk_select2_kernel, then pass 2 on its own grid
+    int tk_ks = 0;                 // list slots per lane: ceil(k / 8) * 8
+    int tk_grid2 = 0;              // pass 2: TT * tk_chunks workgroups
+    bool tk_norm = false;          // the prediction is wanted: a dense launch first (its partials carry the softmax max / denominator)
+    float* tk_part = nullptr;      // pass-1 lists [segments][2 * KS][kBT]
+    float* dense_part = nullptr;   // the dense partials when tk_norm
+    int dense_rows = 0;
+    TopkSelectArgs sel;
 };
 
 // Device copy of the partial-slot lists of one work decomposition (depends only on TT, NT).
@@ -83,10 +88,18 @@ struct vosprop_ctx {
     bool timing = false;
     std::vector<hipEvent_t> tev;   // pairs (start, stop), created on demand
     size_t tev_used = 0;
-    float* tk_thr = nullptr;       // top-k scratch (allocated when cfg.topk > 0)
-    float* tk_m = nullptr;
+    // top-k scratch (grown on demand by propagate(): sizes depend on the number of sampled frames)
+    float* tk_thr = nullptr;       // [TT*256] group threshold (pass 2)
+    float* tk_thr_elem = nullptr;  // [TT*256] element threshold (combine)
+    unsigned* tk_bitmap = nullptr; // [TT][words]
+    size_t tk_bitmap_bytes = 0;
+    float* tk_part = nullptr;      // pass-1 lists
+    size_t tk_part_bytes = 0;
+    float* tk_dump = nullptr;      // [TT*256][2][chunks][cap][16]
+    unsigned* tk_dump_r = nullptr;
     unsigned* tk_cnt = nullptr;
-    uint2* tk_cand = nullptr;
+    size_t tk_dump_groups = 0;     // capacity in groups (= TT*256*2*chunks*cap)
+    size_t tk_cnt_units = 0;
     // video state
     bool in_video = false;
     int frame_idx = 0;
@@ -359,8 +372,19 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
     static const bool no_skew = getenv("VOSPROP_DENSE_SKEW") && atoi(getenv("VOSPROP_DENSE_SKEW")) == 0;
     PropArgs a = a_in;
     a.no_skew = no_skew ? 1 : 0;
-    if (mode == 1) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 1>), grid, block, 0, s, a); return; }
-    if (mode == 2) { hipLaunchKernelGGL((prop_bf16_kernel<false, false, 2>), grid, block, 0, s, a); return; }
+    if (mode == 1) {      // top-k pass 1 (list partials): one instantiation per list length
+        switch (lp.tk_ks) {
+            case 8: hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false, 1, 8>), grid, block, 0, s, a); break;
+            case 16: hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false, 1, 16>), grid, block, 0, s, a); break;
+            case 24: hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false, 1, 24>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false, 1, 32>), grid, block, 0, s, a); break;
+        }
+        return;
+    }
+    if (mode == 2) {      // top-k pass 2 (marked tiles only)
+        hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false, 2, 8>), dim3(lp.tk_grid2), block, 0, s, a);
+        return;
+    }
     if (a.feat_f32) {   // VOSPROP_PREC_F32: the parity kernel (prop_f32.h)
         if (lp.prob) {
             if (lp.lab_lo) hipLaunchKernelGGL((prop_f32_kernel<true, true>), grid, block, 0, s, a);
@@ -409,15 +433,44 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
     }
 }
 
-// The propagation kernel(s) of one step: dense = one launch; top-k = pass 1, select, pass 2.
+// The propagation kernel(s) of one step: dense = one launch; top-k = pass 1, select, pass 2 (and, in front of them, a dense
+// launch for the softmax max / denominators when the caller wants the normalised prediction, not just the mask).
 void launch_prop(const vosprop_ctx* ctx, const LastProp& lp, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     if (lp.topk == 0) { launch_prop_mode(lp, lp.args, 0, s, e0, e1); return; }
+    if (lp.tk_norm) {
+        LastProp dl = lp;
+        dl.topk = 0;
+        dl.no_l = false;
+        PropArgs ad = lp.args;
+        ad.part = lp.dense_part;
+        ad.part_rows = lp.dense_rows;
+        launch_prop_mode(dl, ad, 0, s);
+    }
     PropArgs a1 = lp.args;
-    a1.part_rows = lp.rows_pass1;
+    a1.part = lp.tk_part;
+    a1.part_rows = 2 * lp.tk_ks;
     launch_prop_mode(lp, a1, 1, s);
-    hipLaunchKernelGGL(topk_select_kernel, dim3((ctx->HWp + 63) / 64), dim3(256), 0, s, lp.args.part, lp.d_off, lp.d_list,
-                       lp.topk, ctx->HW, ctx->HWp, ctx->tk_thr, ctx->tk_m, ctx->tk_cnt);
+    const dim3 sgrid(ctx->TT * 4), sblock(256);
+    switch (lp.tk_ks) {
+        case 8: hipLaunchKernelGGL((topk_select2_kernel<8>), sgrid, sblock, 0, s, lp.sel); break;
+        case 16: hipLaunchKernelGGL((topk_select2_kernel<16>), sgrid, sblock, 0, s, lp.sel); break;
+        case 24: hipLaunchKernelGGL((topk_select2_kernel<24>), sgrid, sblock, 0, s, lp.sel); break;
+        default: hipLaunchKernelGGL((topk_select2_kernel<32>), sgrid, sblock, 0, s, lp.sel); break;
+    }
     launch_prop_mode(lp, lp.args, 2, s);
+}
+
+// device buffer of at least `bytes` (grow-only)
+template <typename T>
+int ensure_buf(vosprop_ctx* ctx, T** p, size_t* have, size_t bytes, hipStream_t s) {
+    if (bytes <= *have) return VOSPROP_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(s));      // work in flight may still use the old buffer
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    HIP_TRY(ctx, hipMalloc((void**)p, bytes));
+    *have = bytes;
+    return VOSPROP_OK;
 }
 
 // One propagation: sampled frames `idx` (history indices, ring slot = idx % cap) against the target slot.
@@ -470,14 +523,65 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     lp.prob = prob;
     lp.lab_lo = topk ? false : lab_lo;
     lp.topk = topk;
-    lp.rows_pass1 = 1 + 2 * kTopkMax;
-    lp.d_off = plan->d_off;
-    lp.d_list = plan->d_list;
-    const int rows_alloc = topk ? lp.rows_pass1 : 2 + d;
-    rc = ensure_part(ctx, (size_t)plan->n_parts * rows_alloc * kBT * sizeof(float));
+    rc = ensure_part(ctx, (size_t)plan->n_parts * (2 + d) * kBT * sizeof(float));
     if (rc) return rc;
     a.part = ctx->part;
-    a.part_rows = topk ? 2 : 2 + d;
+    a.part_rows = 2 + d;
+    if (topk) {
+        // ---- top-k (prop_dense.h TK 1 / 2): sizes follow the number of reference tiles NT = n_ref * tiles ----
+        const int NT = n_ref * ctx->tiles;
+        if (NT > 65536 || ctx->tiles > 65535) return fail(ctx, VOSPROP_E_UNSUPPORTED, "top-k: more than 65 536 reference tiles");
+        const int KS = (topk + 7) / 8 * 8;
+        int bits = 1;
+        while ((1 << bits) < 2 * NT) ++bits;                       // (stream index << 1 | half)
+        const int words = (NT + 31) / 32;
+        int chunks = 256 / ctx->TT;                                 // workgroups of pass 2 per target tile: fill the chip once ...
+        const int need_chunks = (NT + kTkListCap - 1) / kTkListCap; // ... and never more marked tiles per workgroup than its list holds
+        if (chunks < need_chunks) chunks = need_chunks;
+        if (chunks < 1) chunks = 1;
+        const size_t cols = (size_t)ctx->TT * kBT;
+        const size_t units = cols * 2 * chunks, groups = units * KS;
+        if (!ctx->tk_thr) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->tk_thr, cols * sizeof(float)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->tk_thr_elem, cols * sizeof(float)));
+        }
+        rc = ensure_buf(ctx, &ctx->tk_bitmap, &ctx->tk_bitmap_bytes, (size_t)ctx->TT * words * 4, s);
+        if (!rc) rc = ensure_buf(ctx, &ctx->tk_part, &ctx->tk_part_bytes, (size_t)plan->n_parts * 2 * KS * kBT * sizeof(float), s);
+        if (rc) return rc;
+        if (groups > ctx->tk_dump_groups || units > ctx->tk_cnt_units) {
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            if (ctx->tk_dump) (void)hipFree(ctx->tk_dump);
+            if (ctx->tk_dump_r) (void)hipFree(ctx->tk_dump_r);
+            if (ctx->tk_cnt) (void)hipFree(ctx->tk_cnt);
+            ctx->tk_dump = nullptr; ctx->tk_dump_r = nullptr; ctx->tk_cnt = nullptr;
+            ctx->tk_dump_groups = ctx->tk_cnt_units = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->tk_dump, groups * 16 * sizeof(float)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->tk_dump_r, groups * sizeof(unsigned)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->tk_cnt, units * sizeof(unsigned)));
+            ctx->tk_dump_groups = groups;
+            ctx->tk_cnt_units = units;
+        }
+        lp.tk_ks = KS;
+        lp.tk_grid2 = ctx->TT * chunks;
+        lp.tk_norm = !ctx->mask_only;
+        lp.tk_part = ctx->tk_part;
+        lp.dense_part = ctx->part;
+        lp.dense_rows = 2 + d;
+        a.tk_idx_bits = bits;
+        a.tk_bitmap = ctx->tk_bitmap;
+        a.tk_words = words;
+        a.tk_bitmap_words = ctx->TT * words;
+        a.tk_chunks = chunks;
+        a.tk_cap = KS;
+        a.tk_dump = ctx->tk_dump;
+        a.tk_dump_r = ctx->tk_dump_r;
+        a.tk_cnt = ctx->tk_cnt;
+        memset(&lp.sel, 0, sizeof(lp.sel));
+        lp.sel.part = ctx->tk_part;
+        lp.sel.plist_off = plan->d_off;
+        lp.sel.k = topk; lp.sel.HW = ctx->HW; lp.sel.bits = bits; lp.sel.words = words;
+        lp.sel.thr_grp = ctx->tk_thr; lp.sel.thr_elem = ctx->tk_thr_elem; lp.sel.bitmap = ctx->tk_bitmap;
+    }
     lp.materialise = ctx->cfg.materialise != 0;
     static const bool keep_l = getenv("VOSPROP_KEEP_L") != nullptr;           // A/B: always accumulate the denominators
     static const bool two_burst_l = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
@@ -497,9 +601,6 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     }
     a.tk_k = topk;
     a.tk_thr = ctx->tk_thr;
-    a.tk_m = ctx->tk_m;
-    a.tk_cnt = ctx->tk_cnt;
-    a.tk_cand = ctx->tk_cand;
     // in-situ timing: event pairs ride on every `stride`-th eligible launch (VOSPROP_TIMING_STRIDE, default 1 = all of them)
     static const int tstride = getenv("VOSPROP_TIMING_STRIDE") ? std::max(1, atoi(getenv("VOSPROP_TIMING_STRIDE"))) : 1;
     const bool eligible = ctx->timing && !f32 && !topk && !prob && !lab_lo && !lp.materialise;   // (either NEED_L form)
@@ -520,12 +621,15 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     if (topk) {
         TopkCombineArgs ca;
         memset(&ca, 0, sizeof(ca));
-        ca.part = ctx->part; ca.plist_off = plan->d_off; ca.plist = plan->d_list;
-        ca.thr = ctx->tk_thr; ca.mfin = ctx->tk_m; ca.cnt = ctx->tk_cnt; ca.cand = ctx->tk_cand;
+        ca.thr_elem = ctx->tk_thr_elem; ca.dump = ctx->tk_dump; ca.dump_r = ctx->tk_dump_r; ca.cnt = ctx->tk_cnt;
         ca.cls_ring = ring.cls;
+        ca.norm_part = lp.tk_norm ? ctx->part : nullptr;
+        ca.plist_off = plan->d_off;
+        ca.norm_rows = 2 + d;
         for (int n = 0; n < n_ref; ++n) ca.slot[n] = slots[n];
-        ca.k = topk; ca.d = d; ca.HW = ctx->HW; ca.HWp = ctx->HWp; ca.c = a.c;
-        hipLaunchKernelGGL(topk_combine_kernel, cgrid, dim3(256), 0, s, ca, pred, cls, new_lab_hi, new_lab_lo);
+        ca.k = topk; ca.d = d; ca.HW = ctx->HW; ca.HWp = ctx->HWp; ca.n_ref = n_ref; ca.chunks = a.tk_chunks; ca.cap = a.tk_cap;
+        ca.c = a.c;
+        hipLaunchKernelGGL(topk_combine2_kernel, cgrid, dim3(256), 0, s, ca, pred, cls, new_lab_hi, new_lab_lo);
     } else {
         UpArgs up;
         memset(&up, 0, sizeof(up));
@@ -792,13 +896,6 @@ int vosprop_create(vosprop_ctx** out, const vosprop_config* cfg) {
     if (!rc && hipMalloc((void**)&ctx->cls_tmp, (size_t)ctx->HWp) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipHostMalloc((void**)&ctx->stage_host, (size_t)ctx->HWp, hipHostMallocDefault) != hipSuccess) rc = VOSPROP_E_HIP;
     if (!rc && hipEventCreateWithFlags(&ctx->stage_ev, hipEventDisableTiming) != hipSuccess) rc = VOSPROP_E_HIP;
-    if (!rc && cfg->topk > 0) {
-        if (hipMalloc((void**)&ctx->tk_thr, (size_t)ctx->HWp * 4) != hipSuccess ||
-            hipMalloc((void**)&ctx->tk_m, (size_t)ctx->HWp * 4) != hipSuccess ||
-            hipMalloc((void**)&ctx->tk_cnt, (size_t)ctx->HWp * 4) != hipSuccess ||
-            hipMalloc((void**)&ctx->tk_cand, (size_t)ctx->HWp * kTopkCap * sizeof(uint2)) != hipSuccess)
-            rc = VOSPROP_E_HIP;
-    }
     if (rc) { vosprop_destroy(ctx); return rc; }
     *out = ctx;
     return VOSPROP_OK;
@@ -827,9 +924,12 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     if (ctx->stage_ev) (void)hipEventDestroy(ctx->stage_ev);
     for (hipEvent_t e : ctx->tev) (void)hipEventDestroy(e);
     if (ctx->tk_thr) (void)hipFree(ctx->tk_thr);
-    if (ctx->tk_m) (void)hipFree(ctx->tk_m);
+    if (ctx->tk_thr_elem) (void)hipFree(ctx->tk_thr_elem);
+    if (ctx->tk_bitmap) (void)hipFree(ctx->tk_bitmap);
+    if (ctx->tk_part) (void)hipFree(ctx->tk_part);
+    if (ctx->tk_dump) (void)hipFree(ctx->tk_dump);
+    if (ctx->tk_dump_r) (void)hipFree(ctx->tk_dump_r);
     if (ctx->tk_cnt) (void)hipFree(ctx->tk_cnt);
-    if (ctx->tk_cand) (void)hipFree(ctx->tk_cand);
     delete ctx;
 }
 

@@ -308,28 +308,10 @@ __device__ __forceinline__ void label_mfmas(const LabFrag<LAB_LO>& lab, const bf
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Top-k variant (NOT in the reference): per target pixel keep the k largest entries of the
-// weighted affinity A[.,t] = P[.,t] w[.,t], zero the rest, no renormalisation (k >= N*HW reproduces the dense result).
-// Ranking by A is ranking by the exponent E = S_w c - gQ_t c (the softmax max and denominator are column constants), so:
-//   pass 1 (MODE 1): no exponentials.  Every lane keeps, sorted in registers, the kTopkMax largest GROUP maxima it has seen
-//           (a group = the 16 rows of one tile a lane owns) and the column max of the raw scores.  The k-th largest group
-//           maximum G_k of a column is a lower bound of its k-th largest element, and at most 16k elements reach it.
-//   pass 2 (MODE 2): exact softmax denominators against the now known column max (no rescale path), and every element
-//           with E >= G_k is appended to a per-pixel candidate list (rare: ~k..2k per pixel); topk_combine_kernel picks
-//           the k largest candidates and sums them per class.
-struct TopkList {
-    float v[kTopkMax];   // descending
-};
-
+// small VALU helpers shared with prop_dense.h
 __device__ __forceinline__ float vmaxf(float a, float b) {
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float vminf(float a, float b) {
-    float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ float max16v(const float (&v)[16]) {
@@ -345,75 +327,11 @@ __device__ __forceinline__ float max16v(const float (&v)[16]) {
     return r;
 }
 
-__device__ __forceinline__ void mask_tail_rows(f32x16& S, int h, int rows_valid) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (acc_row(r, h) >= rows_valid) S[r] = kNegBig;
-}
-
-// LW = log2 of the prior tile (prior_tile<true>): the weighted exponent the top-k ranks by is E = S c + LW.
-// insert x into the first KS slots of the descending list: ONE v_med3 per slot, bottom up (new v[i] = med3(v[i-1], v[i], x): v[i]
-// if x is below it, x if it lands here, v[i-1] if it lands above), then v[0] = max(v[0], x)
-template <int KS>
-__device__ __forceinline__ void topk_insert(TopkList& lst, float x) {
-#pragma unroll
-    for (int i = KS - 1; i >= 1; --i) lst.v[i] = __builtin_amdgcn_fmed3f(lst.v[i - 1], lst.v[i], x);
-    lst.v[0] = vmaxf(lst.v[0], x);
-}
-
-// slots8 = ceil(k / 8): only the first 8 * slots8 list slots are maintained (the k-th largest group maximum needs k of them)
-__device__ __forceinline__ void tile_topk_pass1(f32x16& S, const float (&LW)[16], float& colmax, TopkList& lst, int h, float c,
-                                                bool tail, int rows_valid, int slots8) {
-    if (tail) {
-        asm volatile("; tail tile" ::: "memory");
-        mask_tail_rows(S, h, rows_valid);
-    }
-    float E[16], Sr[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        E[r] = __builtin_fmaf(S[r], c, LW[r]);
-        Sr[r] = S[r];
-    }
-    colmax = vmaxf(colmax, max16v(Sr));
-    const float x = max16v(E);
-    if (slots8 == 1) topk_insert<8>(lst, x);          // wave-uniform
-    else if (slots8 == 2) topk_insert<16>(lst, x);
-    else if (slots8 == 3) topk_insert<24>(lst, x);
-    else topk_insert<kTopkMax>(lst, x);
-}
-
-__device__ __forceinline__ void tile_topk_pass2(f32x16& S, const float (&LW)[16], float mc, float& lsum, int h, float c,
-                                                float thr, bool tail, int rows_valid, unsigned row_base, int t,
-                                                const PropArgs& A) {
-    if (tail) {
-        asm volatile("; tail tile" ::: "memory");
-        mask_tail_rows(S, h, rows_valid);
-    }
-    float E[16];
-    float l0 = 0.0f, l1 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        l0 += __builtin_amdgcn_exp2f(__builtin_fmaf(S[r], c, -mc));
-        l1 += __builtin_amdgcn_exp2f(__builtin_fmaf(S[r + 1], c, -mc));
-        E[r] = __builtin_fmaf(S[r], c, LW[r]);
-        E[r + 1] = __builtin_fmaf(S[r + 1], c, LW[r + 1]);
-    }
-    lsum += l0 + l1;
-    if (__any(max16v(E) >= thr)) {
-        asm volatile("; top-k candidates" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (E[r] >= thr && E[r] > -1.0e29f) {   // the second test drops masked padding rows
-                const unsigned idx = atomicAdd(&A.tk_cnt[t], 1u);
-                if (idx < (unsigned)kTopkCap)
-                    A.tk_cand[(size_t)t * kTopkCap + idx] = make_uint2(__float_as_uint(E[r]), row_base + acc_row(r, h));
-            }
-        }
-    }
-}
-
+// The round-1 two-burst schedule of the dense step (MODE must be 0; the shipped dense kernel and both top-k passes are
+// prop_dense.h).  Kept for A/B timing only (VOSPROP_DENSE_TWO_BURST=1): same arithmetic, same results.
 template <bool PROB, bool LAB_LO, int MODE>
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArgs A) {
+    static_assert(MODE == 0, "the top-k passes moved to prop_dense.h (TK = 1 / 2)");
     __shared__ __attribute__((aligned(16))) unsigned char smem[kRing4 * kLdsBuf];
     // per-lane constants of the prior (target-side MFMA fragment and g Q_t c for both sigmas): needed twice per 9 tiles, so they
     // live in LDS (written and read by the same lane), not in 10 registers
@@ -501,19 +419,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             }
         }
 
-        TopkList lst;            // MODE 1 only
-        const int tk_slots8 = __builtin_amdgcn_readfirstlane((A.tk_k + 7) >> 3);
-        float tk_thr = 3.0e38f;  // MODE 2 only
-        if (MODE == 1) {
-#pragma unroll
-            for (int i = 0; i < kTopkMax; ++i) lst.v[i] = -3.0e38f;
-        }
         ColState st;
         st.m = kNegBig;
-        if (MODE == 2) {
-            st.m = A.tk_m[t_ld];
-            if (t < A.HW) tk_thr = A.tk_thr[t];
-        }
         st.l = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st.Y[r] = 0.0f;
@@ -659,27 +566,19 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
             STAMP_AT(4);   // 4: prefetch issue   (5: max + rescale decision, 6: exps + sums inside tile_softmax)
             if (!PROB && need_w) {       // wave-uniform, 2 of 9 tiles at N = 9
                 asm volatile("; prior tile" ::: "memory");
-                prior_tile<MODE != 0>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c, s_kq[sparse ? 1 : 0][tid], Wt);
+                prior_tile<false>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c, s_kq[sparse ? 1 : 0][tid], Wt);
                 need_w = false;
             }
             const bool tail = ragged && ctile == TPF - 1;
             if (VOSPROP_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(1);
-            if (MODE == 0) {
-                tile_softmax<PROB>(h, S, pa, st, c, tail, rows_last STAMP_PASS);
-                lab_prev = lab;
-            } else if (MODE == 1) {
-                tile_topk_pass1(S, Wt, st.m, lst, h, c, tail, rows_last, tk_slots8);
-            } else {
-                tile_topk_pass2(S, Wt, st.m * c, st.l, h, c, tk_thr, tail, rows_last,
-                                (unsigned)(cn * A.HWp + ctile * kTileR), t, A);
-            }
+            tile_softmax<PROB>(h, S, pa, st, c, tail, rows_last STAMP_PASS);
+            lab_prev = lab;
             if (VOSPROP_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(0);
             STAMP_AT(7);   // 7: pack + label MFMAs
             fr.prefetch_hi(lbn, j, h);
             // this wave's pieces of tile p+2 have landed; the 3 of tile p+3 may stay in flight (loads return in order).  Top-k
             // pass 2 also issues atomics and stores, which share the counter: it waits for everything
-            if (MODE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             if (++cn == N) {        // next pixel tile: a new prior tile
                 cn = 0;
                 ++ctile;
@@ -711,27 +610,17 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_bf16_kernel(const PropArg
                 atomicAdd(&A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + k], tsum[k]);
 #endif
 
-        // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns (dense); (m, 2 x kTopkMax group maxima)
-        // in top-k pass 1; (m, l) in top-k pass 2 ----
+        // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
         float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + j;
-        if (MODE == 1) {
-            const float mm = half_max(st.m);
-            if (h == 0) part[0] = mm;
+        const float lsum = half_sum(st.l);
+        if (h == 0) {
+            part[0] = st.m;
+            part[kBT] = lsum;
+        }
 #pragma unroll
-            for (int i = 0; i < kTopkMax; ++i) part[(size_t)(1 + h * kTopkMax + i) * kBT] = lst.v[i];
-        } else {
-            const float lsum = half_sum(st.l);
-            if (h == 0) {
-                part[0] = st.m;
-                part[kBT] = lsum;
-            }
-            if (MODE == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cls = acc_row(r, h);
-                    if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int cls = acc_row(r, h);
+            if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
         }
     }
 }

@@ -34,18 +34,22 @@ constexpr int kRing5 = 6;   // LDS ring slots of the dense kernel (135 168 B + 2
 constexpr int kRingLast = (kRing5 - 1) * kLdsBuf;
 constexpr float kAlarmExp = 8.0f;   // log2(kSumThrV3)
 
-// rows 0..15 of one tile's softmax against the running max (mc = m c), sequential form (rescale path and the segment's last tile)
-template <bool PROB>
+// rows 0..15 of one tile's softmax against the running max (mc = m c), sequential form (rescale path and the segment's last tile).
+// FUSED (the no-denominator form): Wt holds log2 w - m c and the weighted probability is ONE exponential, a = 2^(S c + Wt).
+template <bool PROB, bool FUSED = false>
 __device__ __forceinline__ void softmax_rows(const f32x16& Sp, const float (&Wt)[16], float c, float mc, float& lt0, float& lt1,
                                              bf16x8& pk0, bf16x8& pk1) {
     lt0 = 0.0f;
     lt1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        const float qa = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[r], c, -mc));
-        const float qb = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[r + 1], c, -mc));
+        const float qa = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[r], c, FUSED ? Wt[r] : -mc));
+        const float qb = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[r + 1], c, FUSED ? Wt[r + 1] : -mc));
         bf16_t ha, hb;
-        if (PROB) {       // the denominator sees the numbers the label product sees (columns sum to 1, see prop_bf16.h)
+        if (FUSED) {
+            ha = (bf16_t)qa;
+            hb = (bf16_t)qb;
+        } else if (PROB) {       // the denominator sees the numbers the label product sees (columns sum to 1, see prop_bf16.h)
             ha = (bf16_t)qa;
             hb = (bf16_t)qb;
             lt0 += (float)ha;
@@ -70,12 +74,35 @@ __device__ __forceinline__ void softmax_rows(const f32x16& Sp, const float (&Wt)
 // scale every class of a column alike, so the arg-max - all that vosprop_step's mask and new label depend on - does not see them;
 // the per-tile sums that also served as the overflow alarm of the optimistic softmax become a running max (v_max3: 8 instructions
 // per tile instead of 16 adds).  The partial's l row is written as 0 and combine_kernel does not divide (engine.hip propagate).
-template <bool PROB, bool LAB_LO, int MAT = 0, bool NEED_L = true>
+// [r3] With no denominator there is no use for the un-weighted probability either: the prior tile is kept as LM = log2 w - m c and
+// the weighted probability is ONE exponential, a = 2^(S c + LM) - fma + exp per score instead of fma + exp + mul, and no
+// exponentials at all in a prior tile (16 fma).  Same value up to rounding: 2^(x) 2^(y) vs 2^(x + y), |x + y| < 2^8 => relative
+// difference <= 2^-16, far inside the bf16 packing that follows; underflow happens where the product underflowed (log2 w <= 0).
+// When the running max moves (rare) LM is rebuilt from the tile's coordinates (they are still in its ring slot).
+//
+// [r3] TK = 1 / 2: the two passes of the TOP-K variant (not in the reference; definition in aux_kernels.h)
+// on this kernel's pipeline - same staging, ring, barriers and MFMA chain; only what happens in the gaps of the chain differs, and
+// neither pass has an exponential, a label product or a running max:
+//   TK = 1  every (reference tile, half) GROUP of 16 scores a lane owns gives one number, the maximum of its weighted exponents
+//           E = S c + log2 w; the lane keeps the KS largest of them, sorted, each with its stream index r and half h packed into
+//           the low mantissa bits (tk_idx_bits; one v_and_or).  16 fma + 8 max3 in gaps 0-7, the KS v_med3 of the insertion in gaps
+//           8-15: 24 + KS vector instructions per tile against the dense form's 48.  topk_select2_kernel merges the lists: the k-th
+//           largest group maximum G_k bounds the k-th largest element from below, and every element >= G_k lies in one of the
+//           (at most k, ties aside) groups whose maximum is >= G_k - whose tiles it marks in a bitmap per target tile.
+//   TK = 2  re-scores ONLY the marked tiles (workgroup = one of tk_chunks equal shares of a target tile's marked tiles, listed in
+//           LDS by the prologue): the same MFMAs on the same bytes give the same E bit for bit, so a lane recognises its
+//           candidate groups by the same packed number (>= tk_thr[t]) and writes the group's 16 exponents + r to a slot of its
+//           own: no atomics, no counters shared between lanes.  topk_combine2_kernel takes the k largest exactly.
+template <bool PROB, bool LAB_LO, int MAT = 0, bool NEED_L = true, int TK = 0, int KS = 8>
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropArgs A) {
     static_assert(NEED_L || (!PROB && !LAB_LO && MAT == 0), "denominators may only be dropped in plain label mode");
+    static_assert(TK == 0 || (!PROB && !LAB_LO && MAT == 0 && !NEED_L), "the top-k passes are label-mode, mask-only forms");
     __shared__ __attribute__((aligned(16))) unsigned char smem[kRing5 * kLdsBuf];
     __shared__ __attribute__((aligned(16))) bf16x8 s_bx[2][kWaves * 64];   // per-lane prior constants (see prop_bf16.h)
     __shared__ float s_kq[2][kWaves * 64];
+    // TK 2: this workgroup's share of its target tile's marked reference tiles, (frame << 16 | pixel tile) per entry, in walk order
+    __shared__ unsigned s_list[TK == 2 ? kTkListCap : 1];
+    __shared__ int s_scan[kWaves];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -123,7 +150,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         third_tile_stride = kLdsCoord;
         third_lane = lane * 16;
         third_lds = kOffCoord;
-    } else if (wave == 2 || wave == 3) {
+    } else if ((wave == 2 || wave == 3) && TK == 0) {      // (the top-k passes read no labels: these waves repeat piece 1)
         third_base = (const unsigned char*)A.lab_hi + (wave - 2) * 1024;
         third_slot_stride = (size_t)TPF * kLdsLab;
         third_tile_stride = kLdsLab;
@@ -152,14 +179,63 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
     const unsigned to = my_slot * (unsigned)third_slot_stride;
     const unsigned char* const feat_base = (const unsigned char*)A.feat_ring;
 
-    const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
+    // TK 2 has no segment table: workgroup b is share (b % tk_chunks) of target tile (b / tk_chunks)
+    const int seg0 = TK == 2 ? 0 : A.seg_off[blockIdx.x], seg1 = TK == 2 ? 1 : A.seg_off[blockIdx.x + 1];
+    if (TK == 1) {      // pass 1 also clears the bitmaps topk_select2_kernel will mark (it runs after this kernel on the stream)
+        for (int i = blockIdx.x * (kWaves * 64) + tid; i < A.tk_bitmap_words; i += gridDim.x * (kWaves * 64)) A.tk_bitmap[i] = 0u;
+    }
 #ifdef VOSPROP_STAMP
     unsigned long long t_seg = 0, rt0 = 0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");   // 100 MHz wall clock: launch ramp / tail
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_seg)::"memory");
 #endif
     for (int si = seg0; si < seg1; ++si) {
-        const Segment sg = A.segs[si];
+        Segment sg;
+        if (TK == 2) {
+            // ---- the walk list of this workgroup: set bits [lo, hi) of its target tile's bitmap, in stream order ----
+            sg.tt = (int)blockIdx.x / A.tk_chunks;
+            sg.slot = (int)blockIdx.x % A.tk_chunks;      // (the share; there is no partial slot in this pass)
+            const unsigned* bm = A.tk_bitmap + (size_t)sg.tt * A.tk_words;
+            const int wpt = (A.tk_words + kWaves * 64 - 1) / (kWaves * 64);      // words per thread, a contiguous run each
+            const int w0 = tid * wpt, w1 = w0 + wpt < A.tk_words ? w0 + wpt : A.tk_words;
+            int cnt_t = 0;
+            for (int wd = w0; wd < w1; ++wd) cnt_t += __builtin_popcount(bm[wd]);
+            int incl = cnt_t;      // inclusive scan over the wave, then over the eight wave totals
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(incl, o);
+                if (lane >= o) incl += u;
+            }
+            if (lane == 63) s_scan[wave] = incl;
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                const int tw = s_scan[w];
+                if (w < wave) base += tw;
+                total += tw;
+            }
+            const int lo = (int)((long long)total * sg.slot / A.tk_chunks), hi = (int)((long long)total * (sg.slot + 1) / A.tk_chunks);
+            int rank = base + incl - cnt_t;      // set bits in front of this thread's words
+            for (int wd = w0; wd < w1; ++wd) {
+                unsigned bits = bm[wd];
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    if (rank >= lo && rank < hi && rank - lo < kTkListCap) {
+                        const unsigned r = (unsigned)(wd * 32 + b);
+                        const unsigned pt = r / (unsigned)A.n_ref;
+                        s_list[rank - lo] = ((r - pt * (unsigned)A.n_ref) << 16) | pt;
+                    }
+                    ++rank;
+                }
+            }
+            __syncthreads();
+            sg.r_lo = 0;
+            sg.n_steps = hi - lo < kTkListCap ? hi - lo : kTkListCap;
+        } else {
+            sg = A.segs[si];
+        }
         const int tt = __builtin_amdgcn_readfirstlane(sg.tt);
         const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);
         const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
@@ -180,6 +256,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         const int t = tt * kBT + wave * kColsPerWave + j_l;
         const int t_ld = t < A.target_rows ? t : A.target_rows - 1;
         const bf16_t* trow = A.target_feat + (size_t)t_ld * kC + h_l * 8;
+        if (TK == 2 && n_steps <= 0) {      // nothing marked in this share (wave-uniform)
+            A.tk_cnt[((size_t)t * 2 + h_l) * A.tk_chunks + part_slot] = 0u;
+            continue;
+        }
         bf16x8 Bt[16];
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) Bt[ks] = *(const bf16x8*)(trow + ks * 16);
@@ -219,13 +299,27 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         st.l = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st.Y[r] = 0.0f;
-        float Wt[16];
+        float Wt[16];      // prior tile of the tile being finished: w (NEED_L) or LM = log2 w - m c (no-denominator form)
 #pragma unroll
         for (int r = 0; r < 16; ++r) Wt[r] = 0.0f;
+        constexpr bool FUSED = !NEED_L;
+        bool w_sparse = false;      // sigma class Wt was built with (FUSED: the rescale path rebuilds LM against the new max)
 
         // ---- staging cursor (frame inner) and the three pieces of a tile ----
         int sn = 0, stile = 0;
+        int sidx = 0;      // TK 2: position of the staging cursor in the walk list
+        auto list_at = [&](int i) __attribute__((always_inline)) -> unsigned {      // entry i of the walk list, clamped to its end
+            const int ii = i < n_steps ? i : n_steps - 1;
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)s_list[TK == 2 ? ii : 0]);
+        };
         auto stage_seek = [&](int step) {
+            if (TK == 2) {
+                sidx = step;
+                const unsigned e = list_at(sidx);
+                stile = (int)(e & 0xFFFFu);
+                sn = (int)(e >> 16);
+                return;
+            }
             stile = (r_lo + step) / N;
             sn = (r_lo + step) - stile * N;
         };
@@ -256,6 +350,13 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             else glds16s2(third_lane, so_third, third_base, lds, third_lds);
         };
         auto stage_advance = [&]() __attribute__((always_inline)) {   // next tile of the stream; stays on the last one at its end
+            if (TK == 2) {
+                ++sidx;
+                const unsigned e = list_at(sidx);
+                stile = (int)(e & 0xFFFFu);
+                sn = (int)(e >> 16);
+                return;
+            }
             int nn = sn + 1, ns = stile;
             if (nn == N) {
                 nn = 0;
@@ -306,12 +407,30 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #endif
         // compute cursor (pixel tile, frame) of the tile whose SCORES are being computed
         int ctile = r_lo / N, cn = r_lo - ctile * N;
+        int cidx = 0;      // TK 2: position of the compute cursor in the walk list
+        if (TK == 2) {
+            const unsigned e = list_at(0);
+            ctile = (int)(e & 0xFFFFu);
+            cn = (int)(e >> 16);
+        }
         bool sparse = (A.sparse_mask >> cn) & 1ull;
         bool need_w = !PROB;
+        // ---- top-k state ----
+        float tkv[TK == 1 ? KS : 1];      // TK 1: the KS largest packed group maxima this lane has seen, descending
+        if (TK == 1) {
+#pragma unroll
+            for (int i = 0; i < KS; ++i) tkv[i] = kTkDummy;
+        }
+        const unsigned tk_keep = ~((1u << A.tk_idx_bits) - 1u);      // mantissa bits a packed group maximum keeps
+        float tk_thr = 3.0e38f;                                      // TK 2: a group whose packed maximum reaches this is dumped
+        int tk_cur = 0;                                              // TK 2: groups this lane has dumped
+        if (TK == 2 && t < A.HW) tk_thr = A.tk_thr[t];
+        float Ek[TK == 2 ? 16 : 1];                                  // TK 2: the weighted exponents of the tile being finished
+        int crs_prev = -1;                                           // stream index of the tile being finished
 
         AFrag<PROB> fr;
         if (MAT != 2) fr.prefetch(smem, j, h);
-        int crs = r_lo;     // stream index of the tile being scored (MAT 1: where its score tile goes)
+        int crs = TK == 2 ? ctile * N + cn : r_lo;     // stream index of the tile being scored (MAT 1: where its score tile goes)
 
         f32x16 S0, S1;
 #pragma unroll
@@ -342,10 +461,39 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st.Y[r] *= sc;
                 st.m = mn;
-                softmax_rows<PROB>(Sp, Wt, c, mn * c, lt0, lt1, pk0, pk1);
+                // LM of this tile against the new max, from the tile's own coordinates (slot s_prv holds tile p-1 until step p+2)
+                if (FUSED) prior_tile<true>(smem + s_prv, j, h, s_bx[w_sparse ? 1 : 0][tid], c, s_kq[w_sparse ? 1 : 0][tid] + mn * c, Wt);
+                softmax_rows<PROB, FUSED>(Sp, Wt, c, mn * c, lt0, lt1, pk0, pk1);
             }
             if (NEED_L) st.l += lt0 + lt1;
             label_mfmas<LAB_LO>(labp, pk0, pk1, st.Y);
+        };
+
+        // TK 2: tile p-1's group of this lane is a candidate group of its column (its packed maximum x reaches the column's
+        // threshold - the very number pass 1 computed, bit for bit): the group's 16 exponents and its stream index go to the
+        // lane's next slot.  The stores are asm statements so that their NUMBER is known (5, when any lane of the wave stores):
+        // the step's closing s_waitcnt counts them.  Returns whether the wave stored.
+        static_assert(TK == 0 || kStageA, "the top-k passes assume the older-wave staging scheme (their vmcnt counts)");
+        auto tk_dump = [&](float x) __attribute__((always_inline)) -> bool {
+            const bool hit = x >= tk_thr && tk_cur < A.tk_cap;
+            const bool any = __any(hit);
+            if (any) {
+                if (hit) {
+                    const size_t slot_i = (((size_t)t * 2 + h) * A.tk_chunks + part_slot) * A.tk_cap + tk_cur;
+                    const float* dst = A.tk_dump + slot_i * 16;
+                    const unsigned* dstr = A.tk_dump_r + slot_i;
+                    const f32x4 v0 = {Ek[0], Ek[1], Ek[2], Ek[3]}, v1 = {Ek[4], Ek[5], Ek[6], Ek[7]};
+                    const f32x4 v2 = {Ek[8], Ek[9], Ek[10], Ek[11]}, v3 = {Ek[12], Ek[13], Ek[14], Ek[15]};
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\t"
+                                 "global_store_dwordx4 %0, %3, off offset:32\n\tglobal_store_dwordx4 %0, %4, off offset:48\n\t"
+                                 "global_store_dword %5, %6, off"
+                                 :
+                                 : "v"(dst), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(dstr), "v"((unsigned)crs_prev)
+                                 : "memory");
+                    ++tk_cur;
+                }
+            }
+            return any;
         };
 
         // one step: scores of tile p into S, softmax of tile p-1 (scores Sp, labels labp) in the gaps of the chain
@@ -358,7 +506,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             if (STAGER) stage_bases();
             LabFrag<LAB_LO> labp;
             const float mc = st.m * c;
-            float lt0 = NEED_L ? 0.0f : kNegBig, lt1 = 0.0f, qprev = 0.0f;
+            float lt0 = TK != 0 ? kTkDummy : NEED_L ? 0.0f : kNegBig, lt1 = 0.0f, qprev = 0.0f;
             bf16x8 pk0, pk1;
             const unsigned char* arow = lb + j * kRowB + h * 16;
             const unsigned char* nrow = lbn + j * kRowB + h * 16;
@@ -396,6 +544,32 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 }
 #endif
                 if (MAT == 1) continue;                        // score tiles only
+                if (TK != 0) {
+                    // ---- top-k passes: weighted exponents of tile p-1 and their group maximum (no exponential) ----
+                    if (ks < 8) {
+                        const float e0 = __builtin_fmaf(Sp[2 * ks], c, Wt[2 * ks]);
+                        const float e1 = __builtin_fmaf(Sp[2 * ks + 1], c, Wt[2 * ks + 1]);
+                        if (TK == 2) {
+                            Ek[2 * ks] = e0;
+                            Ek[2 * ks + 1] = e1;
+                        }
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(lt0) : "v"(lt0), "v"(e0), "v"(e1));      // lt0 = the group's maximum
+                    } else {
+                        if (ks == 8)      // the maximum with (stream index, half) in its low mantissa bits: ONE v_and_or_b32
+                            lt1 = __uint_as_float((__float_as_uint(lt0) & tk_keep) | ((((unsigned)crs_prev << 1) | (unsigned)h) & ~tk_keep));
+                        if (TK == 1) {
+                            // insertion into the descending list, bottom up, KS / 8 slots per gap:
+                            // new v[i] = med3(v[i-1], v[i], x): v[i] if x is below it, x if it lands here, v[i-1] if it lands above
+                            constexpr int per = KS / 8;
+#pragma unroll
+                            for (int q2 = 0; q2 < per; ++q2) {
+                                const int i = KS - 1 - ((ks - 8) * per + q2);
+                                if (i >= 1) tkv[i] = __builtin_amdgcn_fmed3f(tkv[i - 1], tkv[i], lt1);
+                                else tkv[0] = vmaxf(tkv[0], lt1);
+                            }
+                        }
+                    }
+                } else {
                 if (ks == 10) labp.load(smem + s_prv, lane);   // labels of tile p-1, for the label MFMAs after the chain
                 // row ks of the previous tile
 #if VOSPROP_DABLATE & 1
@@ -403,7 +577,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 if (ks == 15) { pk0 = Bt[0]; pk1 = Bt[1]; }
                 if (false)
 #else
-                const float q = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[ks], c, -mc));
+                const float q = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[ks], c, FUSED ? Wt[ks] : -mc));
 #endif
                 if (PROB) {
                     if (ks & 1) {
@@ -422,7 +596,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                     } else if (ks & 1) {      // overflow alarm only, from the raw scores (off the exponential's dependency chain):
                         lt0 = __builtin_fmaxf(__builtin_fmaxf(lt0, Sp[ks - 1]), Sp[ks]);   // lt0 = max of the tile's scores
                     }
-                    const float aq = q * Wt[ks];
+                    const float aq = FUSED ? q : q * Wt[ks];
                     if (ks & 1) {
                         if (ks < 8) { pk0[ks - 1] = (bf16_t)qprev; pk0[ks] = (bf16_t)aq; }
                         else { pk1[ks - 9] = (bf16_t)qprev; pk1[ks - 8] = (bf16_t)aq; }
@@ -430,6 +604,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                         qprev = aq;
                     }
                 }
+                }      // TK == 0
                 if (MID_BARRIER && ks == 7) {
                     // this wave's pieces of tile p+2 (issued in step p-1) have landed: only the two of this step may be in flight
                     if (STAGER) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
@@ -445,12 +620,23 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             }
             // the packed weights are "used" here, in the chain's basic block: hipcc otherwise sinks the multiplies and packings of the
             // fast path below the rescale branch, out of the MFMA shadow
-            if (MAT != 1) asm volatile("" : "+v"(pk0), "+v"(pk1));
+            if (MAT != 1 && TK == 0) asm volatile("" : "+v"(pk0), "+v"(pk1));
+            if (TK != 0) asm volatile("" : "+v"(lt1));
+            if (TK == 1) {      // ... and the list: its insertion belongs in the shadow of gaps 8-15, not in a burst behind the chain
+#pragma unroll
+                for (int i = 0; i < KS; ++i) asm volatile("" : "+v"(tkv[i]));
+            }
+            if (TK == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(Ek[i]));
+            }
 #ifdef VOSPROP_STAMP
             STAMP_AT(2);   // 2: gaps 8-15
 #endif
             if (STAGER) stage_advance();
-            if (MAT != 1) finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
+            if (MAT != 1 && TK == 0) finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
+            bool tk_stored = false;      // TK 2: this wave issued the five dump stores in this step (they count in vmcnt)
+            if (TK == 2) tk_stored = tk_dump(lt1);
 #ifdef VOSPROP_STAMP
             STAMP_AT(3);   // 3: rescale check + label MFMAs
 #endif
@@ -472,6 +658,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 __builtin_nontemporal_store(o0, (bf16x8*)dst);
                 __builtin_nontemporal_store(o1, (bf16x8*)(dst + 8));
             }
+            crs_prev = crs;
             ++crs;
             // tile p: padded rows of a frame's last tile never enter the softmax (wave-uniform, rare)
             if (ragged && ctile == TPF - 1) {
@@ -483,10 +670,20 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             // the prior tile of tile p (used from the next step on; tile p-1 is finished)
             if (!PROB && need_w) {
                 asm volatile("; prior tile" ::: "memory");
-                prior_tile<false>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c, s_kq[sparse ? 1 : 0][tid], Wt);
+                prior_tile<FUSED>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c,
+                                  s_kq[sparse ? 1 : 0][tid] + (FUSED && TK == 0 ? st.m * c : 0.0f), Wt);      // (top-k: log2 w itself)
+                w_sparse = sparse;
                 need_w = false;
             }
-            if (++cn == N) {
+            if (TK == 2) {      // the next marked tile: anywhere further down the stream
+                ++cidx;
+                const unsigned e = list_at(cidx);
+                const int nt = (int)(e & 0xFFFFu);
+                if (nt != ctile) need_w = true;
+                ctile = nt;
+                cn = (int)(e >> 16);
+                crs = ctile * N + cn;
+            } else if (++cn == N) {
                 cn = 0;
                 ++ctile;
                 need_w = !PROB;
@@ -507,7 +704,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 STAMP_AT(4);   // 4: tail mask, prior tile, cursor
 #endif
                 if (!MID_BARRIER) {
-                    if (STAGER && kStageA) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                    // TK 2: the five dump stores of this step were issued after its five pieces: they are the youngest
+                    if (STAGER && kStageA && TK == 2 && tk_stored) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                    else if (STAGER && kStageA) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                     else if (STAGER) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
 #ifdef VOSPROP_STAMP
                     STAMP_AT(5);   // 5: wait for the own pieces of tile p+2
@@ -558,11 +757,29 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         }
         // the segment's last tile has no chain to hide under (its labels sit in slot s_prv after the last ring_advance)
         auto drain = [&](const f32x16& Sp) __attribute__((always_inline)) {
+            if (TK != 0) {      // the last tile's group: exponents, maximum, packed index; list insertion / dump
+                float g = kTkDummy;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_fmaf(Sp[r], c, Wt[r]);
+                    if (TK == 2) Ek[r] = e;
+                    g = vmaxf(g, e);
+                }
+                const float x = __uint_as_float((__float_as_uint(g) & tk_keep) | ((((unsigned)crs_prev << 1) | (unsigned)h) & ~tk_keep));
+                if (TK == 1) {
+#pragma unroll
+                    for (int i = KS - 1; i >= 1; --i) tkv[i] = __builtin_amdgcn_fmed3f(tkv[i - 1], tkv[i], x);
+                    tkv[0] = vmaxf(tkv[0], x);
+                } else {
+                    (void)tk_dump(x);
+                }
+                return;
+            }
             float lt0, lt1;
             bf16x8 pk0, pk1;
             LabFrag<LAB_LO> labp;
             labp.load(smem + s_prv, lane);
-            softmax_rows<PROB>(Sp, Wt, c, st.m * c, lt0, lt1, pk0, pk1);
+            softmax_rows<PROB, FUSED>(Sp, Wt, c, st.m * c, lt0, lt1, pk0, pk1);
             if (!NEED_L) {      // the alarm of this form looks at the scores
                 float sv[16];
 #pragma unroll
@@ -591,6 +808,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #endif
 
         if (MAT == 1) continue;
+        if (TK == 2) {      // how many groups this lane dumped in this share (every lane writes: no memset between steps)
+            A.tk_cnt[((size_t)t * 2 + h) * A.tk_chunks + part_slot] = (unsigned)tk_cur;
+            continue;
+        }
+        if (TK == 1) {      // this segment's lists: rows (half, rank) x 256 columns
+            float* pl = A.part + ((size_t)part_slot * A.part_rows + (size_t)h * KS) * kBT + wave * kColsPerWave + j;
+#pragma unroll
+            for (int i = 0; i < KS; ++i) pl[(size_t)i * kBT] = tkv[i];
+            continue;
+        }
         // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
         int tid_e = tid;
         asm volatile("" : "+v"(tid_e));

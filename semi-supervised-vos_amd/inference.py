@@ -152,13 +152,15 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
     net = VOSNet(model=model)
     net = load_model(net, resume)
     dtype = _DTYPES[encoder_dtype] if Config.DEVICE.type == 'cuda' else None
-    net.prepare_for_inference(Config.DEVICE, dtype, miopen_find=miopen_find)
+    # an f16 / bf16 encoder hands its features to the bf16 propagation path as bf16 (read in place, no push launch per frame)
+    fdt = torch.bfloat16 if (dtype is not None and propagation_precision == 'bf16') else None
+    net.prepare_for_inference(Config.DEVICE, dtype, miopen_find=miopen_find, feature_dtype=fdt)
     additional = None
     if inference_strategy == 'multimodel':      # reference src/inference.py:65-71
         if not additional_resume:
             raise click.UsageError("--inference-strategy multimodel needs --additional-model")
         additional = load_model(VOSNet(model=additional_model_type), additional_resume)
-        additional.prepare_for_inference(Config.DEVICE, dtype, miopen_find=miopen_find)
+        additional.prepare_for_inference(Config.DEVICE, dtype, miopen_find=miopen_find, feature_dtype=fdt)
 
     if Config.DEVICE.type == 'cuda' and encoder_graph:
         # full batches of one resolution replay a captured HIP graph; everything else (last batch of a video, another

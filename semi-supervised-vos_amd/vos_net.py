@@ -208,6 +208,7 @@ class VOSNet(nn.Module):
                 nn.init.zeros_(m.bias)
 
     fused = False
+    feature_dtype = None      # set by prepare_for_inference(feature_dtype=...): element type the features are handed over in
 
     def forward(self, x):
         if self.fused:
@@ -217,6 +218,8 @@ class VOSNet(nn.Module):
                 x = stage(x)
             if self.model != 'resnet18':
                 x = conv_bias_act(x, self.adjust_dim, self.adjust_dim.bias, None, relu=False)
+            if self.feature_dtype is not None and x.dtype != self.feature_dtype:
+                x = x.to(self.feature_dtype)      # one element-wise pass over the batch, inside the captured graph
             return x
         x = self.backbone(x)
         if self.model != 'resnet18':
@@ -254,7 +257,8 @@ class VOSNet(nn.Module):
             self.adjust_dim, self.bn256 = fold(self.adjust_dim, self.bn256), nn.Identity()
         return self
 
-    def prepare_for_inference(self, device, dtype=torch.bfloat16, fold_bn=True, fuse_epilogue=True, miopen_find=False):
+    def prepare_for_inference(self, device, dtype=torch.bfloat16, fold_bn=True, fuse_epilogue=True, miopen_find=False,
+                              feature_dtype=None):
         """eval + folded BatchNorm + channels_last + reduced-precision weights on `device` (the reference runs the
         encoder under torch.cuda.amp.autocast = fp16 on GPU, inference_utils.py:35,52).  fuse_epilogue: bias + residual add +
         ReLU after every convolution as one pass (bias_act_) instead of two or three element-wise kernels.  miopen_find: let
@@ -262,7 +266,12 @@ class VOSNet(nn.Module):
         of taking the immediate-mode pick - measured +16 % end to end at batch 32 on MI355X (1 225 -> 1 425 frames/s in
         bench.py), but the search costs 10-20 s per new batch shape in every process (it is not cached across processes on this
         stack), more than a whole DAVIS-sized job takes: off by default, on in bench.py (search in the untimed warm-up) and
-        with `main.py inference --miopen-find` for long jobs."""
+        with `main.py inference --miopen-find` for long jobs.  feature_dtype (fused path only): the features leave the encoder in
+        this type - torch.bfloat16 for an f16 encoder feeding the bf16 propagation path: the engine's ring is bf16 either way
+        (the same round-to-nearest-even conversion its push kernel would do per frame), but bf16 channels-last features are read
+        IN PLACE by the propagation kernel (vosprop_step: no push launch per frame), and converting the whole look-ahead batch is
+        one pass inside the captured graph (~1 us per 480p frame)."""
+        self.feature_dtype = feature_dtype
         if miopen_find and torch.device(device).type == 'cuda':
             torch.backends.cudnn.benchmark = True
         self.eval().to(device)
