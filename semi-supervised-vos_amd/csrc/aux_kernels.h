@@ -297,92 +297,189 @@ __device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t*
 //   pass 2   re-scores the marked tiles only and dumps, per lane, the 16 exponents of every group that reaches thr_grp;
 //   combine2 takes the k largest dumped exponents of a column exactly, sums 2^E per class, arg-maxes, packs the new labels.
 // No atomics on values, no counters shared between lanes, no second full scoring pass.
-template <int KS>
-__device__ __forceinline__ void topk_list_insert(float (&lst)[KS], float x) {
+// ---- k-th largest of up to 64 * NV values spread over a wave, by radix selection on sortable keys ----
+// key(x) orders like x (unsigned compare); 0 = "no value".  Bit by bit from the top: keep the bit if at least k keys reach the
+// candidate; a count is NV ballots + scalar popcounts (no LDS, no shuffles).  Stops as soon as EXACTLY k keys reach the candidate
+// (then those k are the k largest, whatever the lower bits).  Returns T with: {key >= T, key != 0} = the k largest, ties of the k-th
+// included (what the oracle's `S >= kth` keeps); fewer than k values: T = 0 (all of them).
+__device__ __forceinline__ unsigned sortable_key(float x) {
+    const unsigned u = __float_as_uint(x);
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(unsigned k) {
+    return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu));
+}
+template <int NV>
+__device__ __forceinline__ unsigned wave_kth_largest(const unsigned (&key)[NV], int nv, int k) {
+    unsigned T = 0u;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned cand = T | (1u << b);
+        int c = 0;
 #pragma unroll
-    for (int q = KS - 1; q >= 1; --q) lst[q] = __builtin_amdgcn_fmed3f(lst[q - 1], lst[q], x);
-    lst[0] = fmaxf(lst[0], x);
+        for (int j = 0; j < NV; ++j)
+            if (j < nv) c += __builtin_popcountll(__ballot(key[j] >= cand));
+        if (c >= k) {
+            T = cand;
+            if (c == k) break;
+        }
+    }
+    return T;
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned w = (unsigned)__shfl_xor((int)v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {      // fixed order: the same bits on every run
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
 struct TopkSelectArgs {
-    const float* part;        // pass-1 lists: [slot][2 * KS][kBT]
+    const float* part;        // pass-1 lists: [slot][kBT columns][2 * KS] (a lane's list is contiguous)
     const int* plist_off;     // slots of target tile tt: plist_off[tt] .. plist_off[tt + 1] - 1 (consecutive, engine.hip get_plan)
-    int k, HW, bits, words;   // bits: index bits of a packed maximum; words: bitmap words per target tile
-    float c;
+    int k, ks, HW, bits, words;   // ks: list slots per lane; bits: index bits of a packed maximum; words: bitmap words per target tile
     float* thr_grp;           // [TT*256]
     float* thr_elem;          // [TT*256]
     unsigned* bitmap;         // [TT][words], cleared by pass 1
 };
 
-// grid = TT * 4, block = 256 = 64 target pixels x 4 lanes (a block's pixels belong to ONE target tile: 256 = 4 x 64)
-template <int KS>
-__global__ __launch_bounds__(256) void topk_select2_kernel(const TopkSelectArgs a) {
-    __shared__ float lsts[3][KS][64];
+constexpr int kTkSelCols = 8;      // columns (= waves) per block of the select kernel
+constexpr int kTkSelCap = 512;     // candidate keys a column can carry through LDS (8 per lane)
+
+// k-th largest of ONE key per lane (the common case after compaction): 2-3 instructions per bit
+__device__ __forceinline__ unsigned wave_kth_largest_1(unsigned key, int k) {
+    unsigned T = 0u;
+    for (int b = 31; b >= 0; --b) {
+        const unsigned cand = T | (1u << b);
+        const int c = __builtin_popcountll(__ballot(key >= cand));
+        if (c >= k) {
+            T = cand;
+            if (c == k) break;
+        }
+    }
+    return T;
+}
+
+// One WAVE per target pixel.  The column's (slots x 2 x KS) packed group maxima are STREAMED, 64 at a time (consecutive lanes read
+// consecutive floats); nothing about their number is assumed:
+//   sweep 1  every lane keeps the maximum of the values it sees; the k-th largest of the 64 lane maxima, L0, is a lower bound of
+//            v_k (k lanes hold a value >= L0);
+//   sweep 2  the values >= L0 - 2 D(L0) (a superset of everything that can reach thr_grp = v_k - 2 D(v_k), see above) are compacted
+//            into LDS with ballot prefixes - normally a few dozen;
+//   then     v_k = their k-th largest by radix selection (8 keys per lane at most), and the lanes mark the tiles of the candidates
+//            that reach thr_grp.
+// Should more than kTkSelCap values pass sweep 2 (lists that leave most lanes without a real value), L0 is replaced by the exact
+// v_k from a streamed radix selection (32 sweeps; correct, slow, not seen on the bench shapes).
+// grid = TT * 256 / 8, block = 8 waves (the block's pixels belong to ONE target tile).
+__global__ __launch_bounds__(kTkSelCols * 64) void topk_select2_kernel(const TopkSelectArgs a) {
     __shared__ unsigned bm[2048];      // this block's marks (words <= 2048: NT <= 65 536, checked on the host)
-    const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
-    const int t = blockIdx.x * 64 + col;
-    const int tt = (blockIdx.x * 64) / kBT, tcol = (blockIdx.x * 64) % kBT + col;
-    for (int i = tid; i < a.words; i += 256) bm[i] = 0u;
-    const bool live = t < a.HW;
-    float lst[KS];
-#pragma unroll
-    for (int i = 0; i < KS; ++i) lst[i] = kTkDummy;
-    if (live) {
-        const int u0 = a.plist_off[tt], u1 = a.plist_off[tt + 1];
-        const size_t ustride = (size_t)(2 * KS) * kBT;
-        for (int u = u0 + g; u < u1; u += 4) {      // this lane's quarter of the slots; a slot's two lists fetched whole
-            const float* pu = a.part + (size_t)u * ustride + tcol;
-            float v[2][KS];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int i = 0; i < KS; ++i) v[hh][i] = pu[(size_t)(hh * KS + i) * kBT];
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                for (int i = 0; i < KS; ++i) {
-                    if (v[hh][i] <= lst[KS - 1]) break;      // both lists are descending
-                    topk_list_insert<KS>(lst, v[hh][i]);
-                }
-            }
-        }
-    }
-    if (g > 0) {
-#pragma unroll
-        for (int i = 0; i < KS; ++i) lsts[g - 1][i][col] = lst[i];
-    }
+    __shared__ unsigned carry[kTkSelCols][kTkSelCap];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t = blockIdx.x * kTkSelCols + wv;
+    const int tt = (blockIdx.x * kTkSelCols) / kBT, tcol = (blockIdx.x * kTkSelCols) % kBT + wv;
+    for (int i = tid; i < a.words; i += kTkSelCols * 64) bm[i] = 0u;
     __syncthreads();
-    if (g == 0) {
-        float tg = 3.0e38f, te = 3.0e38f;      // dead columns: nothing reaches the threshold
-        if (live) {
-            for (int gg = 0; gg < 3; ++gg)
-                for (int i = 0; i < KS; ++i) {
-                    const float x = lsts[gg][i][col];
-                    if (x <= lst[KS - 1]) break;
-                    topk_list_insert<KS>(lst, x);
-                }
-            float vk = lst[0];
+    float tg = 3.0e38f, te = 3.0e38f;      // dead columns: nothing reaches the threshold
+    if (t < a.HW) {                        // (wave-uniform)
+        const int u0 = a.plist_off[tt], u1 = a.plist_off[tt + 1];
+        const int two_ks = 2 * a.ks;
+        const int nvals = (u1 - u0) * two_ks;
+        const unsigned kfloor = sortable_key(-1.0e37f);      // "no group" fillers are not values
+        const float dscale = __builtin_amdgcn_exp2f((float)(a.bits - 22));
+        // value v = 64 i + lane is entry (v % 2KS) of slot (v / 2KS): a cursor (slot, entry) that advances by 64 values per sweep
+        // step without a division
+        const int q64 = 64 / two_ks, r64 = 64 - q64 * two_ks;
+        const int sl0 = lane / two_ks, idx0 = lane - sl0 * two_ks;
+        int c_sl = sl0, c_idx = idx0;
+        auto rewind = [&]() { c_sl = sl0; c_idx = idx0; };
+        auto next_key = [&]() -> unsigned {      // the cursor's value (0 past the end or for a filler), then advance
+            unsigned kk = 0u;
+            if (c_sl < u1 - u0) {
+                kk = sortable_key(a.part[((size_t)(u0 + c_sl) * kBT + tcol) * two_ks + c_idx]);
+                kk = kk > kfloor ? kk : 0u;
+            }
+            c_sl += q64;
+            c_idx += r64;
+            if (c_idx >= two_ks) { c_idx -= two_ks; ++c_sl; }
+            return kk;
+        };
+        unsigned mx = 0u;
+        for (int v0 = 0; v0 < nvals; v0 += 64) {
+            const unsigned kk = next_key();
+            mx = kk > mx ? kk : mx;
+        }
+        unsigned L0 = wave_kth_largest_1(mx, a.k);
+        if (L0) L0 = wave_min_u32(mx >= L0 && mx ? mx : 0xFFFFFFFFu);      // the k-th largest lane maximum itself
+        int n_c = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            unsigned Lc = 0u;
+            if (L0) {
+                const float l0 = key_value(L0);
+                Lc = sortable_key(l0 - 2.0f * fmaxf(fabsf(l0), 1.0e-30f) * dscale);
+            }
+            int base = 0;
+            rewind();
+            for (int v0 = 0; v0 < nvals; v0 += 64) {
+                const unsigned kk = next_key();
+                const bool keep = kk != 0u && kk >= Lc;
+                const unsigned long long m = __ballot(keep);
+                const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (keep && pos < kTkSelCap) carry[wv][pos] = kk;
+                base += __builtin_popcountll(m);
+            }
+            n_c = base;
+            if (n_c <= kTkSelCap || attempt == 1) break;
+            // too many: the exact k-th largest by a streamed radix selection becomes the bound
+            unsigned T = 0u;
+            for (int b = 31; b >= 0; --b) {
+                const unsigned cand = T | (1u << b);
+                int c = 0;
+                rewind();
+                for (int v0 = 0; v0 < nvals; v0 += 64) c += __builtin_popcountll(__ballot(next_key() >= cand));
+                if (c >= a.k) T = cand;
+            }
+            L0 = T;
+        }
+        n_c = n_c < kTkSelCap ? n_c : kTkSelCap;
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        constexpr int NVc = kTkSelCap / 64;
+        unsigned key[NVc];
 #pragma unroll
-            for (int q = 1; q < KS; ++q)
-                if (q < a.k) vk = lst[q];
-            const float D = fmaxf(fabsf(vk), 1.0e-30f) * __builtin_amdgcn_exp2f((float)(a.bits - 22));
-            te = vk - D;
-            tg = vk - 2.0f * D;
-            const unsigned imask = (1u << a.bits) - 1u;
+        for (int j = 0; j < NVc; ++j) key[j] = 64 * j + lane < n_c ? carry[wv][64 * j + lane] : 0u;
+        const int nvc = (n_c + 63) >> 6;
+        const unsigned T = nvc <= 1 ? wave_kth_largest_1(key[0], a.k) : wave_kth_largest<NVc>(key, nvc, a.k);
+        unsigned mine = 0xFFFFFFFFu;
 #pragma unroll
-            for (int q = 0; q < KS; ++q) {
-                if (lst[q] >= tg && lst[q] > -1.0e37f) {      // (not a "no group" filler)
-                    const unsigned r = (__float_as_uint(lst[q]) & imask) >> 1;
-                    atomicOr(&bm[r >> 5], 1u << (r & 31));
-                }
+        for (int j = 0; j < NVc; ++j)
+            if (key[j] >= T && key[j] != 0u) mine = key[j] < mine ? key[j] : mine;
+        mine = wave_min_u32(mine);
+        // v_k: the k-th largest packed maximum (the smallest one kept); fewer than k real groups: everything real is a candidate
+        const float vk = (mine == 0xFFFFFFFFu || n_c < a.k) ? kTkDummy : key_value(mine);
+        const float D = fmaxf(fabsf(vk), 1.0e-30f) * dscale;
+        te = vk - D;
+        tg = vk - 2.0f * D;
+        const unsigned kg = sortable_key(tg), imask = (1u << a.bits) - 1u;
+#pragma unroll
+        for (int j = 0; j < NVc; ++j) {
+            if (key[j] != 0u && key[j] >= kg) {
+                const unsigned r = (__float_as_uint(key_value(key[j])) & imask) >> 1;
+                atomicOr(&bm[r >> 5], 1u << (r & 31));
             }
         }
+    }
+    if (lane == 0) {
         a.thr_grp[t] = tg;
         a.thr_elem[t] = te;
     }
     __syncthreads();
     unsigned* gb = a.bitmap + (size_t)tt * a.words;
-    for (int i = tid; i < a.words; i += 256)
+    for (int i = tid; i < a.words; i += kTkSelCols * 64)
         if (bm[i]) atomicOr(&gb[i], bm[i]);
 }
 
@@ -398,75 +495,98 @@ struct TopkCombineArgs {
     int slot[kMaxRef];
     int k, d, HW, HWp, n_ref, chunks, cap;
     float c;
+    int debug;                // dev switch (VOSPROP_TK_DEBUG): 1 = radix selection on all keys, no lane-maximum bound / compaction
 };
 
-// grid = ceil(HW/64), block = 256 = 64 target pixels x 4 lanes; all 256 then pack the block's label tiles.
-__global__ __launch_bounds__(256) void topk_combine2_kernel(const TopkCombineArgs a, float* __restrict__ pred,
-                                                            uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi,
-                                                            bf16_t* __restrict__ lab_lo) {
-    __shared__ float outv[kMaxClasses][64];
-    __shared__ float outg[3][kMaxClasses][64];      // per-class sums of lanes 1..3 of a pixel
-    __shared__ float lsts[3][kTopkMax][64];         // sorted candidate lists of lanes 1..3
-    __shared__ float red[2][64];                    // [0] = tau, [1] = reference exponent
-    __shared__ uint8_t clsv[64];
-    const int tid = threadIdx.x, col = tid & 63, g = tid >> 6;
-    const int t = blockIdx.x * 64 + col;
-    const bool live = t < a.HW;
-    if (g == 0) {
-        for (int k = 0; k < a.d; ++k) outv[k][col] = 0.0f;
-        clsv[col] = 0;
-    } else {
-        for (int k = 0; k < a.d; ++k) outg[g - 1][k][col] = 0.0f;
-    }
-    float lst[kTopkMax];
-#pragma unroll
-    for (int i = 0; i < kTopkMax; ++i) lst[i] = kTkDummy;
+constexpr int kTkComNV = 10;      // groups per quarter-wave the combine kernel holds: 40 dumped groups (640 exponents) per pixel
+constexpr int kTkComWaves = 16;   // waves = pixels per block: half a 32-pixel label tile
+constexpr int kTkComCap = 128;    // candidate keys a pixel carries through LDS (2 per lane)
+
+// One WAVE per target pixel: lane = (group g % 4, element e) holds the exponents of up to 40 dumped groups (normally ~20).  The k
+// largest: lane maxima give a lower bound L0 of the k-th largest (k lanes hold a value >= L0), the few values >= L0 are compacted
+// through LDS and radix-selected (2 keys per lane); the classes of the kept elements come from the class-index ring, the per-class
+// sums from fixed-order wave reductions (reproducible).  grid = ceil(HW / 16), block = 16 waves; 64 threads then pack the block's
+// half of its label tile.  [r3: the first form - four lanes per pixel walking the groups with sorted insertion - took 57 us on the
+// bench clip and 159 us on flat logits, more than pass 2 itself]
+__global__ __launch_bounds__(kTkComWaves * 64) void topk_combine2_kernel(const TopkCombineArgs a, float* __restrict__ pred,
+                                                                          uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi,
+                                                                          bf16_t* __restrict__ lab_lo) {
+    __shared__ unsigned tab[kTkComWaves][4 * kTkComNV];      // group g of the wave's pixel -> (unit << 8 | index in the unit)
+    __shared__ unsigned carry[kTkComWaves][kTkComCap];
+    __shared__ uint8_t clsv[kTkComWaves];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int e = lane & 15, gq = lane >> 4;
     const float floor_e = -1.0e29f * a.c;      // masked rows (S = -1e30) sit below this
-    const float te = live ? fmaxf(a.thr_elem[t], floor_e) : 3.0e38f;
-    const int n_units = 2 * a.chunks;          // (half, share) pairs of this pixel
-    // phase 1: the k largest exponents among the dumped groups (this lane: every 4th group)
-    if (live) {
-        int gi = 0;
-        for (int u = 0; u < n_units; ++u) {
-            const size_t ub = (size_t)t * n_units + u;
-            unsigned n = a.cnt[ub];
-            if (n > (unsigned)a.cap) n = a.cap;
-            for (unsigned q = 0; q < n; ++q, ++gi) {
-                if ((gi & 3) != g) continue;
-                const f32x4* e4 = (const f32x4*)(a.dump + (ub * a.cap + q) * 16);
-                const f32x4 v0 = e4[0], v1 = e4[1], v2 = e4[2], v3 = e4[3];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float x = e < 4 ? v0[e & 3] : e < 8 ? v1[e & 3] : e < 12 ? v2[e & 3] : v3[e & 3];
-                    if (x >= te && x > lst[kTopkMax - 1]) topk_list_insert<kTopkMax>(lst, x);
-                }
-            }
+    const int n_units = 2 * a.chunks;          // (half, share) pairs of a pixel: <= 64 (host)
+    const int t = blockIdx.x * kTkComWaves + wv;
+    if (lane == 0) clsv[wv] = 0;
+    if (t < a.HW) {      // (wave-uniform)
+        // ---- the pixel's dumped groups: counts per unit, exclusive prefix, table group -> (unit, index) ----
+        int cu = 0;
+        if (lane < n_units) {
+            cu = (int)a.cnt[(size_t)t * n_units + lane];
+            cu = cu < a.cap ? cu : a.cap;
         }
-    }
-    if (g > 0) {
+        int incl = cu;
 #pragma unroll
-        for (int i = 0; i < kTopkMax; ++i) lsts[g - 1][i][col] = lst[i];
-    }
-    __syncthreads();
-    if (g == 0 && live) {
-        for (int gg = 0; gg < 3; ++gg)
-            for (int i = 0; i < kTopkMax; ++i) {
-                const float x = lsts[gg][i][col];
-                if (x <= lst[kTopkMax - 1]) break;      // descending
-                topk_list_insert<kTopkMax>(lst, x);
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o);
+            if (lane >= o) incl += u;
+        }
+        const int before = incl - cu;
+        int total = __shfl(incl, 63);
+        total = total < 4 * kTkComNV ? total : 4 * kTkComNV;      // (more than 40 groups reach the threshold only under mass ties)
+        for (int q = 0; q < cu; ++q)
+            if (before + q < 4 * kTkComNV) tab[wv][before + q] = ((unsigned)lane << 8) | (unsigned)q;
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's own LDS writes have landed (one wave: no barrier needed)
+        __builtin_amdgcn_wave_barrier();
+        const float te = fmaxf(a.thr_elem[t], floor_e);
+        unsigned key[kTkComNV], meta[kTkComNV];
+        float x[kTkComNV];
+        const int nvg = (total + 3) >> 2;
+        unsigned mx = 0u;
+#pragma unroll
+        for (int j = 0; j < kTkComNV; ++j) {
+            key[j] = 0u;
+            meta[j] = 0u;
+            x[j] = 0.0f;
+            const int g = 4 * j + gq;
+            if (g < total) {
+                const unsigned m = tab[wv][g];
+                const size_t gi = ((size_t)t * n_units + (m >> 8)) * a.cap + (m & 0xFFu);
+                x[j] = a.dump[gi * 16 + e];
+                meta[j] = (a.dump_r[gi] << 1) | ((m >> 8) >= (unsigned)a.chunks ? 1u : 0u);      // (stream index, half)
+                if (x[j] >= te) key[j] = sortable_key(x[j]);
             }
-        float tau = lst[0];
+            mx = key[j] > mx ? key[j] : mx;
+        }
+        // ---- the k-th largest exponent ----
+        unsigned L0 = wave_kth_largest_1(mx, a.k);
+        if (L0) L0 = wave_min_u32(mx >= L0 && mx ? mx : 0xFFFFFFFFu);      // the k-th largest lane maximum: a lower bound
+        int base = 0;
 #pragma unroll
-        for (int q = 1; q < kTopkMax; ++q)
-            if (q < a.k) tau = lst[q];
-        red[0][col] = fmaxf(tau, te);      // fewer than k real elements: everything real is kept
-        red[1][col] = lst[0];              // reference exponent of the un-normalised sum: the largest one
-    }
-    __syncthreads();
-    // phase 2: the kept elements, summed per class
-    if (live) {
-        const float tau = red[0][col];
-        float eref = red[1][col], inv = 1.0f;
+        for (int j = 0; j < kTkComNV; ++j) {
+            const bool keep = key[j] != 0u && key[j] >= L0;
+            const unsigned long long m = __ballot(keep);
+            const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (keep && pos < kTkComCap) carry[wv][pos] = key[j];
+            base += __builtin_popcountll(m);
+        }
+        unsigned T;
+        if (base <= kTkComCap && !(a.debug & 1)) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            unsigned k2[2];
+            k2[0] = lane < base ? carry[wv][lane] : 0u;
+            k2[1] = 64 + lane < base ? carry[wv][64 + lane] : 0u;
+            T = base <= 64 ? wave_kth_largest_1(k2[0], a.k) : wave_kth_largest<2>(k2, 2, a.k);
+            T = T > L0 ? T : L0;      // (an early exit leaves T a prefix that separates the k largest CANDIDATES only: below L0 it says
+                                      //  nothing about the keys that were not carried over)
+        } else {
+            T = wave_kth_largest<kTkComNV>(key, nvg, a.k);
+        }
+        // ---- reference exponent and denominator ----
+        float eref, inv = 1.0f;
         if (a.norm_part) {      // the prediction is wanted: the softmax max and denominator of the column, from the dense partials
             const int tt = t / kBT, tcol = t % kBT;
             const int u0 = a.plist_off[tt], u1 = a.plist_off[tt + 1];
@@ -479,49 +599,55 @@ __global__ __launch_bounds__(256) void topk_combine2_kernel(const TopkCombineArg
             }
             eref = M * a.c;
             inv = 1.0f / L;
+        } else {                // un-normalised: against the largest exponent
+            const unsigned top = ~wave_min_u32(~mx);
+            eref = top ? key_value(top) : 0.0f;
         }
-        float (*acc)[64] = g == 0 ? outv : outg[g - 1];
-        int gi = 0;
-        for (int u = 0; u < n_units; ++u) {
-            const size_t ub = (size_t)t * n_units + u;
-            const int hh = u / a.chunks;
-            unsigned n = a.cnt[ub];
-            if (n > (unsigned)a.cap) n = a.cap;
-            for (unsigned q = 0; q < n; ++q, ++gi) {
-                if ((gi & 3) != g) continue;
-                const f32x4* e4 = (const f32x4*)(a.dump + (ub * a.cap + q) * 16);
-                const f32x4 v0 = e4[0], v1 = e4[1], v2 = e4[2], v3 = e4[3];
-                const unsigned r = a.dump_r[ub * a.cap + q];
-                const unsigned pt = r / (unsigned)a.n_ref, fn = r - pt * (unsigned)a.n_ref;
-                if (pt >= (unsigned)(a.HWp / kTileR)) continue;      // (the "no group" filler of a segment's first step)
-                const uint8_t* cr = a.cls_ring + (size_t)a.slot[fn] * a.HWp + pt * kTileR;
+        // ---- the kept elements: class from the class-index ring, weight 2^(E - eref) ----
+        float w[kTkComNV];
+        int kc[kTkComNV];
+        const unsigned tiles = (unsigned)(a.HWp / kTileR);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float x = e < 4 ? v0[e & 3] : e < 8 ? v1[e & 3] : e < 12 ? v2[e & 3] : v3[e & 3];
-                    if (x >= tau && x > floor_e) {
-                        const int kcls = cr[acc_row(e, hh)];
-                        if (kcls < a.d) acc[kcls][col] += __builtin_amdgcn_exp2f(x - eref) * inv;
-                    }
+        for (int j = 0; j < kTkComNV; ++j) {
+            w[j] = 0.0f;
+            kc[j] = -1;
+            if (key[j] != 0u && key[j] >= T) {
+                const unsigned r = meta[j] >> 1, hh = meta[j] & 1u;
+                const unsigned pt = r / (unsigned)a.n_ref, fn = r - pt * (unsigned)a.n_ref;
+                if (pt < tiles) {
+                    kc[j] = a.cls_ring[(size_t)a.slot[fn] * a.HWp + pt * kTileR + acc_row(e, (int)hh)];
+                    w[j] = __builtin_amdgcn_exp2f(x[j] - eref) * inv;
                 }
             }
         }
-    }
-    __syncthreads();
-    if (g == 0 && live) {
         int best = 0;
         float bv = -1.0f;
         for (int k = 0; k < a.d; ++k) {
-            const float v = ((outv[k][col] + outg[0][k][col]) + outg[1][k][col]) + outg[2][k][col];
-            outv[k][col] = v;
-            pred[(size_t)k * a.HW + t] = v;
-            if (v > bv) { bv = v; best = k; }
+            float sk = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kTkComNV; ++j) sk += kc[j] == k ? w[j] : 0.0f;
+            sk = wave_sum_f32(sk);
+            if (lane == 0) pred[(size_t)k * a.HW + t] = sk;
+            if (sk > bv) { bv = sk; best = k; }
         }
-        clsv[col] = (uint8_t)best;
-        cls[t] = (uint8_t)best;
+        if (lane == 0) {
+            clsv[wv] = (uint8_t)best;
+            cls[t] = (uint8_t)best;
+        }
     }
     if (!lab_hi) return;
     __syncthreads();
-    pack_block_labels(outv, clsv, a.d, a.HW, 0, lab_hi, lab_lo);
+    if (tid < 64) {      // the block's half (rows 16 s .. 16 s + 15) of its label tile, MFMA A-operand order (one-hot: label mode only)
+        const int s2 = blockIdx.x & 1, k = tid & 31;
+        bf16x8 oh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int pc = lab_row(s2, tid, q) - 16 * s2;      // pixel within the block
+            const bool on = blockIdx.x * kTkComWaves + pc < a.HW && k < a.d && clsv[pc] == k;
+            oh[q] = (bf16_t)(on ? 1.0f : 0.0f);
+        }
+        *(bf16x8*)(lab_hi + ((size_t)(blockIdx.x >> 1) * 128 + (size_t)s2 * 64 + tid) * 8) = oh;
+    }
 }
 
 // Nearest up-sampling of the class map (reference inference_utils.py:74-75; argmax and nearest

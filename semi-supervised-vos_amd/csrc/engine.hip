@@ -61,6 +61,7 @@ struct Plan {
     int steps_per_wg = 0;     // reference tiles the busiest workgroup walks (stats)
     int n_parts = 0;          // total partial slots = number of segments
     int* d_off = nullptr;     // [TT + 1]
+    std::vector<int> h_off;   // host copy of d_off
     int* d_list = nullptr;    // slot indices, CSR by target tile
     Segment* d_segs = nullptr;
     int* d_seg_off = nullptr; // [grid + 1]
@@ -294,6 +295,7 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
     for (int b = 0; b < p.grid; ++b)
         for (const Segment& sg : per_wg[(size_t)b]) ++off[(size_t)sg.tt + 1];
     for (int tt = 0; tt < TT; ++tt) off[(size_t)tt + 1] += off[(size_t)tt];
+    p.h_off = off;
     std::vector<int> next(off.begin(), off.end() - 1);
     std::vector<Segment> segs;
     std::vector<int> seg_off((size_t)p.grid + 1, 0);
@@ -450,13 +452,7 @@ void launch_prop(const vosprop_ctx* ctx, const LastProp& lp, hipStream_t s, hipE
     a1.part = lp.tk_part;
     a1.part_rows = 2 * lp.tk_ks;
     launch_prop_mode(lp, a1, 1, s);
-    const dim3 sgrid(ctx->TT * 4), sblock(256);
-    switch (lp.tk_ks) {
-        case 8: hipLaunchKernelGGL((topk_select2_kernel<8>), sgrid, sblock, 0, s, lp.sel); break;
-        case 16: hipLaunchKernelGGL((topk_select2_kernel<16>), sgrid, sblock, 0, s, lp.sel); break;
-        case 24: hipLaunchKernelGGL((topk_select2_kernel<24>), sgrid, sblock, 0, s, lp.sel); break;
-        default: hipLaunchKernelGGL((topk_select2_kernel<32>), sgrid, sblock, 0, s, lp.sel); break;
-    }
+    hipLaunchKernelGGL(topk_select2_kernel, dim3(ctx->TT * (kBT / kTkSelCols)), dim3(kTkSelCols * 64), 0, s, lp.sel);
     launch_prop_mode(lp, lp.args, 2, s);
 }
 
@@ -536,9 +532,11 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         while ((1 << bits) < 2 * NT) ++bits;                       // (stream index << 1 | half)
         const int words = (NT + 31) / 32;
         int chunks = 256 / ctx->TT;                                 // workgroups of pass 2 per target tile: fill the chip once ...
+        if (chunks > 32) chunks = 32;                               // (topk_combine2_kernel: one lane per (half, share) unit)
         const int need_chunks = (NT + kTkListCap - 1) / kTkListCap; // ... and never more marked tiles per workgroup than its list holds
         if (chunks < need_chunks) chunks = need_chunks;
         if (chunks < 1) chunks = 1;
+        if (need_chunks > 32) return fail(ctx, VOSPROP_E_UNSUPPORTED, "top-k: more than 32 768 reference tiles");
         const size_t cols = (size_t)ctx->TT * kBT;
         const size_t units = cols * 2 * chunks, groups = units * KS;
         if (!ctx->tk_thr) {
@@ -579,7 +577,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         memset(&lp.sel, 0, sizeof(lp.sel));
         lp.sel.part = ctx->tk_part;
         lp.sel.plist_off = plan->d_off;
-        lp.sel.k = topk; lp.sel.HW = ctx->HW; lp.sel.bits = bits; lp.sel.words = words;
+        lp.sel.k = topk; lp.sel.ks = KS; lp.sel.HW = ctx->HW; lp.sel.bits = bits; lp.sel.words = words;
         lp.sel.thr_grp = ctx->tk_thr; lp.sel.thr_elem = ctx->tk_thr_elem; lp.sel.bitmap = ctx->tk_bitmap;
     }
     lp.materialise = ctx->cfg.materialise != 0;
@@ -629,7 +627,10 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         for (int n = 0; n < n_ref; ++n) ca.slot[n] = slots[n];
         ca.k = topk; ca.d = d; ca.HW = ctx->HW; ca.HWp = ctx->HWp; ca.n_ref = n_ref; ca.chunks = a.tk_chunks; ca.cap = a.tk_cap;
         ca.c = a.c;
-        hipLaunchKernelGGL(topk_combine2_kernel, cgrid, dim3(256), 0, s, ca, pred, cls, new_lab_hi, new_lab_lo);
+        static const int tk_debug = getenv("VOSPROP_TK_DEBUG") ? atoi(getenv("VOSPROP_TK_DEBUG")) : 0;
+        ca.debug = tk_debug;
+        hipLaunchKernelGGL(topk_combine2_kernel, dim3((ctx->HWp + kTkComWaves - 1) / kTkComWaves), dim3(kTkComWaves * 64), 0, s, ca, pred, cls, new_lab_hi,
+                           new_lab_lo);
     } else {
         UpArgs up;
         memset(&up, 0, sizeof(up));
@@ -819,6 +820,24 @@ int vosprop_debug_pointwise_candidates(const void* x, const void* weight, const 
                                   (PwCandidateReport*)rows, cap_rows, &n, repeats, full != 0);
     if (rc == 0) return n;
     return rc == 1 ? VOSPROP_E_INVALID : rc == 3 ? VOSPROP_E_UNSUPPORTED : VOSPROP_E_HIP;
+}
+
+/* test hook (GPU, not part of include/vosprop.h): the top-k thresholds and the number of groups pass 2 dumped per target pixel, of
+ * the last top-k propagation on ctx.  thr_grp / thr_elem: HW floats each; groups: HW ints. */
+int vosprop_debug_topk(vosprop_ctx* ctx, float* thr_grp, float* thr_elem, int* groups) {
+    if (!ctx || !ctx->last.valid || !ctx->last.topk) return VOSPROP_E_STATE;
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(thr_grp, ctx->tk_thr, (size_t)ctx->HW * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(thr_elem, ctx->tk_thr_elem, (size_t)ctx->HW * 4, hipMemcpyDeviceToHost));
+    const int units = 2 * ctx->last.args.tk_chunks;
+    std::vector<unsigned> cnt((size_t)ctx->HW * units);
+    HIP_TRY(ctx, hipMemcpy(cnt.data(), ctx->tk_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+    for (int t = 0; t < ctx->HW; ++t) {
+        int n = 0;
+        for (int u = 0; u < units; ++u) n += (int)cnt[(size_t)t * units + u];
+        groups[t] = n;
+    }
+    return VOSPROP_OK;
 }
 
 /* test hook (no GPU needed): segment table for TT target tiles x NT reference tiles; rows of out = (workgroup, tt, r_lo, n_steps) */

@@ -812,10 +812,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             A.tk_cnt[((size_t)t * 2 + h) * A.tk_chunks + part_slot] = (unsigned)tk_cur;
             continue;
         }
-        if (TK == 1) {      // this segment's lists: rows (half, rank) x 256 columns
-            float* pl = A.part + ((size_t)part_slot * A.part_rows + (size_t)h * KS) * kBT + wave * kColsPerWave + j;
+        if (TK == 1) {      // this segment's lists: 256 columns x (half, rank)
+            float* pl = A.part + (((size_t)part_slot * kBT + wave * kColsPerWave + j) * 2 + h) * KS;      // [slot][column][half][KS]
 #pragma unroll
-            for (int i = 0; i < KS; ++i) pl[(size_t)i * kBT] = tkv[i];
+            for (int i = 0; i < KS; i += 4) *(f32x4*)(pl + i) = f32x4{tkv[i], tkv[i + 1], tkv[i + 2], tkv[i + 3]};
             continue;
         }
         // ---- this segment's partial: rows (m, l, numerators[d]) x 256 columns ----
