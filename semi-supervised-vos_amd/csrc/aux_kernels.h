@@ -350,6 +350,7 @@ struct TopkSelectArgs {
 
 constexpr int kTkSelCols = 8;      // columns (= waves) per block of the select kernel
 constexpr int kTkSelCap = 512;     // candidate keys a column can carry through LDS (8 per lane)
+constexpr int kTkSelRegs = 24;     // sweep steps of a column kept in registers (24 x 64 = 1 536 list entries)
 
 // k-th largest of ONE key per lane (the common case after compaction): 2-3 instructions per bit
 __device__ __forceinline__ unsigned wave_kth_largest_1(unsigned key, int k) {
@@ -397,19 +398,26 @@ __global__ __launch_bounds__(kTkSelCols * 64) void topk_select2_kernel(const Top
         const int sl0 = lane / two_ks, idx0 = lane - sl0 * two_ks;
         int c_sl = sl0, c_idx = idx0;
         auto rewind = [&]() { c_sl = sl0; c_idx = idx0; };
-        auto next_key = [&]() -> unsigned {      // the cursor's value (0 past the end or for a filler), then advance
-            unsigned kk = 0u;
-            if (c_sl < u1 - u0) {
-                kk = sortable_key(a.part[((size_t)(u0 + c_sl) * kBT + tcol) * two_ks + c_idx]);
-                kk = kk > kfloor ? kk : 0u;
-            }
+        auto next_key = [&]() -> unsigned {      // the cursor's value (0 past the end or for a filler), then advance.  The load
+            const bool in = c_sl < u1 - u0;      // itself is unconditional (clamped address): a run of them goes out back to back
+            const int sl = in ? c_sl : 0;
+            unsigned kk = sortable_key(a.part[((size_t)(u0 + sl) * kBT + tcol) * two_ks + c_idx]);
+            kk = in && kk > kfloor ? kk : 0u;
             c_sl += q64;
             c_idx += r64;
             if (c_idx >= two_ks) { c_idx -= two_ks; ++c_sl; }
             return kk;
         };
+        // the first kTkSelRegs sweep steps (64 values each) stay in registers - all of a column at the bench shapes - so sweep 2
+        // re-reads nothing; longer columns stream the rest
+        const int rounds = (nvals + 63) >> 6;
+        unsigned kreg[kTkSelRegs];
+#pragma unroll
+        for (int i = 0; i < kTkSelRegs; ++i) kreg[i] = next_key();      // (past the end: 0)
         unsigned mx = 0u;
-        for (int v0 = 0; v0 < nvals; v0 += 64) {
+#pragma unroll
+        for (int i = 0; i < kTkSelRegs; ++i) mx = kreg[i] > mx ? kreg[i] : mx;
+        for (int i = kTkSelRegs; i < rounds; ++i) {
             const unsigned kk = next_key();
             mx = kk > mx ? kk : mx;
         }
@@ -423,14 +431,23 @@ __global__ __launch_bounds__(kTkSelCols * 64) void topk_select2_kernel(const Top
                 Lc = sortable_key(l0 - 2.0f * fmaxf(fabsf(l0), 1.0e-30f) * dscale);
             }
             int base = 0;
-            rewind();
-            for (int v0 = 0; v0 < nvals; v0 += 64) {
-                const unsigned kk = next_key();
+            auto compact = [&](unsigned kk) {
                 const bool keep = kk != 0u && kk >= Lc;
                 const unsigned long long m = __ballot(keep);
-                const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                if (keep && pos < kTkSelCap) carry[wv][pos] = kk;
-                base += __builtin_popcountll(m);
+                if (m) {      // (wave-uniform: most sweep steps carry nothing over)
+                    const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (keep && pos < kTkSelCap) carry[wv][pos] = kk;
+                    base += __builtin_popcountll(m);
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < kTkSelRegs; ++i) compact(kreg[i]);
+            if (rounds > kTkSelRegs) {
+                rewind();
+                for (int i = 0; i < rounds; ++i) {
+                    const unsigned kk = next_key();
+                    if (i >= kTkSelRegs) compact(kk);
+                }
             }
             n_c = base;
             if (n_c <= kTkSelCap || attempt == 1) break;
@@ -555,7 +572,7 @@ __global__ __launch_bounds__(kTkComWaves * 64) void topk_combine2_kernel(const T
                 const unsigned m = tab[wv][g];
                 const size_t gi = ((size_t)t * n_units + (m >> 8)) * a.cap + (m & 0xFFu);
                 x[j] = a.dump[gi * 16 + e];
-                meta[j] = (a.dump_r[gi] << 1) | ((m >> 8) >= (unsigned)a.chunks ? 1u : 0u);      // (stream index, half)
+                meta[j] = (a.dump_r[gi] << 1) | ((m >> 8) >= (unsigned)a.chunks ? 1u : 0u);      // (frame << 16 | pixel tile, half)
                 if (x[j] >= te) key[j] = sortable_key(x[j]);
             }
             mx = key[j] > mx ? key[j] : mx;
@@ -613,8 +630,8 @@ __global__ __launch_bounds__(kTkComWaves * 64) void topk_combine2_kernel(const T
             kc[j] = -1;
             if (key[j] != 0u && key[j] >= T) {
                 const unsigned r = meta[j] >> 1, hh = meta[j] & 1u;
-                const unsigned pt = r / (unsigned)a.n_ref, fn = r - pt * (unsigned)a.n_ref;
-                if (pt < tiles) {
+                const unsigned pt = r & 0xFFFFu, fn = (r >> 16) & 0x3Fu;
+                if (pt < tiles && fn < (unsigned)a.n_ref) {
                     kc[j] = a.cls_ring[(size_t)a.slot[fn] * a.HWp + pt * kTileR + acc_row(e, (int)hh)];
                     w[j] = __builtin_amdgcn_exp2f(x[j] - eref) * inv;
                 }

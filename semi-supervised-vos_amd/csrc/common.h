@@ -101,7 +101,7 @@ struct PropArgs {
     int tk_chunks;              // pass 2: workgroups that share one target tile's marked tiles
     int tk_cap;                 // pass 2: groups one lane can dump per share
     float* tk_dump;             // [TT*256][2][tk_chunks][tk_cap][16] weighted exponents of the dumped groups
-    unsigned* tk_dump_r;        // [TT*256][2][tk_chunks][tk_cap]     their stream indices
+    unsigned* tk_dump_r;        // [TT*256][2][tk_chunks][tk_cap]     their tiles: frame << 16 | pixel tile
     unsigned* tk_cnt;           // [TT*256][2][tk_chunks]             groups dumped
     int no_skew;                // dense kernel: 1 = both waves of a SIMD keep their barrier at the step end (VOSPROP_DENSE_SKEW=0, A/B only)
     unsigned long long* dbg;    // diagnostic builds only (-DVOSPROP_STAMP): per-wave cycle sums; else nullptr

@@ -427,6 +427,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         if (TK == 2 && t < A.HW) tk_thr = A.tk_thr[t];
         float Ek[TK == 2 ? 16 : 1];                                  // TK 2: the weighted exponents of the tile being finished
         int crs_prev = -1;                                           // stream index of the tile being finished
+        unsigned tkid_prev = 0xFFFFu;                                // TK 2: the same as (frame << 16 | pixel tile)
 
         AFrag<PROB> fr;
         if (MAT != 2) fr.prefetch(smem, j, h);
@@ -482,13 +483,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                     const size_t slot_i = (((size_t)t * 2 + h) * A.tk_chunks + part_slot) * A.tk_cap + tk_cur;
                     const float* dst = A.tk_dump + slot_i * 16;
                     const unsigned* dstr = A.tk_dump_r + slot_i;
+                    // the group's tile as (frame << 16 | pixel tile) - what topk_combine2_kernel looks its rows' classes up with; the
+                    // "no group" of a share's first step (crs_prev = -1) gets an out-of-range pixel tile
+                    const unsigned tk_prev_id = tkid_prev;
                     const f32x4 v0 = {Ek[0], Ek[1], Ek[2], Ek[3]}, v1 = {Ek[4], Ek[5], Ek[6], Ek[7]};
                     const f32x4 v2 = {Ek[8], Ek[9], Ek[10], Ek[11]}, v3 = {Ek[12], Ek[13], Ek[14], Ek[15]};
                     asm volatile("global_store_dwordx4 %0, %1, off\n\tglobal_store_dwordx4 %0, %2, off offset:16\n\t"
                                  "global_store_dwordx4 %0, %3, off offset:32\n\tglobal_store_dwordx4 %0, %4, off offset:48\n\t"
                                  "global_store_dword %5, %6, off"
                                  :
-                                 : "v"(dst), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(dstr), "v"((unsigned)crs_prev)
+                                 : "v"(dst), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(dstr), "v"(tk_prev_id)
                                  : "memory");
                     ++tk_cur;
                 }
@@ -659,6 +663,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 __builtin_nontemporal_store(o1, (bf16x8*)(dst + 8));
             }
             crs_prev = crs;
+            if (TK == 2) tkid_prev = ((unsigned)cn << 16) | (unsigned)ctile;
             ++crs;
             // tile p: padded rows of a frame's last tile never enter the softmax (wave-uniform, rare)
             if (ragged && ctile == TPF - 1) {
