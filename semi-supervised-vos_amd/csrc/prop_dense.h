@@ -303,6 +303,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) Wt[r] = 0.0f;
         constexpr bool FUSED = !NEED_L;
+#ifndef VOSPROP_ROWS_EARLY
+#define VOSPROP_ROWS_EARLY 1      // A/B switch of the row schedule below (step lambda)
+#endif
+        constexpr bool kRowsEarly = FUSED && TK == 0 && VOSPROP_ROWS_EARLY != 0;
         bool w_sparse = false;      // sigma class Wt was built with (FUSED: the rescale path rebuilds LM against the new max)
 
         // ---- staging cursor (frame inner) and the three pieces of a tile ----
@@ -575,38 +579,50 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                     }
                 } else {
                 if (ks == 10) labp.load(smem + s_prv, lane);   // labels of tile p-1, for the label MFMAs after the chain
-                // row ks of the previous tile
+                // rows of the previous tile.  [r3] The mask-only form (3.5 vector instructions per row) does them EARLY - row g in gap
+                // g up to gap 11, two rows in gaps 12 and 13, none in gaps 14 and 15 - so that the last exponentials and packings are
+                // not left standing behind the 16th MFMA, in front of the label MFMAs that wait for them (hipcc otherwise bunches the
+                // last rows there: ~60 exposed cycles per step and wave).
+                auto soft_row = [&](int r) __attribute__((always_inline)) {
 #if VOSPROP_DABLATE & 1
-                const float q = Sp[ks];
-                if (ks == 15) { pk0 = Bt[0]; pk1 = Bt[1]; }
-                if (false)
+                    const float q = Sp[r];
+                    if (r == 15) { pk0 = Bt[0]; pk1 = Bt[1]; }
+                    if (false)
 #else
-                const float q = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[ks], c, FUSED ? Wt[ks] : -mc));
+                    const float q = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[r], c, FUSED ? Wt[r] : -mc));
 #endif
-                if (PROB) {
-                    if (ks & 1) {
-                        const bf16_t ha = (bf16_t)qprev, hb = (bf16_t)q;
-                        lt0 += (float)ha;
-                        lt1 += (float)hb;
-                        if (ks < 8) { pk0[ks - 1] = ha; pk0[ks] = hb; }
-                        else { pk1[ks - 9] = ha; pk1[ks - 8] = hb; }
+                    if (PROB) {
+                        if (r & 1) {
+                            const bf16_t ha = (bf16_t)qprev, hb = (bf16_t)q;
+                            lt0 += (float)ha;
+                            lt1 += (float)hb;
+                            if (r < 8) { pk0[r - 1] = ha; pk0[r] = hb; }
+                            else { pk1[r - 9] = ha; pk1[r - 8] = hb; }
+                        } else {
+                            qprev = q;
+                        }
                     } else {
-                        qprev = q;
+                        if (NEED_L) {
+                            if (r & 1) lt1 += q;
+                            else lt0 += q;
+                        } else if (r & 1) {      // overflow alarm only, from the raw scores (off the exponential's dependency chain):
+                            lt0 = __builtin_fmaxf(__builtin_fmaxf(lt0, Sp[r - 1]), Sp[r]);   // lt0 = max of the tile's scores
+                        }
+                        const float aq = FUSED ? q : q * Wt[r];
+                        if (r & 1) {
+                            if (r < 8) { pk0[r - 1] = (bf16_t)qprev; pk0[r] = (bf16_t)aq; }
+                            else { pk1[r - 9] = (bf16_t)qprev; pk1[r - 8] = (bf16_t)aq; }
+                        } else {
+                            qprev = aq;
+                        }
                     }
+                };
+                if (kRowsEarly) {
+                    if (ks < 12) soft_row(ks);
+                    else if (ks == 12) { soft_row(12); soft_row(13); }
+                    else if (ks == 13) { soft_row(14); soft_row(15); }
                 } else {
-                    if (NEED_L) {
-                        if (ks & 1) lt1 += q;
-                        else lt0 += q;
-                    } else if (ks & 1) {      // overflow alarm only, from the raw scores (off the exponential's dependency chain):
-                        lt0 = __builtin_fmaxf(__builtin_fmaxf(lt0, Sp[ks - 1]), Sp[ks]);   // lt0 = max of the tile's scores
-                    }
-                    const float aq = FUSED ? q : q * Wt[ks];
-                    if (ks & 1) {
-                        if (ks < 8) { pk0[ks - 1] = (bf16_t)qprev; pk0[ks] = (bf16_t)aq; }
-                        else { pk1[ks - 9] = (bf16_t)qprev; pk1[ks - 8] = (bf16_t)aq; }
-                    } else {
-                        qprev = aq;
-                    }
+                    soft_row(ks);
                 }
                 }      // TK == 0
                 if (MID_BARRIER && ks == 7) {
@@ -619,7 +635,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 // of one softmax row, in the MFMA's shadow - hipcc otherwise sinks the multiplies and packings below the chain
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // <= 5 VALU (one of them the exponential)
+                if (kRowsEarly && (ks == 12 || ks == 13)) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // two rows
+                else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // <= 5 VALU (one of them the exponential)
 #endif
             }
             // the packed weights are "used" here, in the chain's basic block: hipcc otherwise sinks the multiplies and packings of the
