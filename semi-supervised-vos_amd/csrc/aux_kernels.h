@@ -340,7 +340,7 @@ __device__ __forceinline__ float wave_sum_f32(float v) {      // fixed order: th
 }
 
 struct TopkSelectArgs {
-    const float* part;        // pass-1 lists: [slot][kBT columns][2 * KS] (a lane's list is contiguous)
+    const float* part;        // pass-1 lists: [target tile][kBT columns][slot rank][2 * KS]: a target pixel's entries are contiguous
     const int* plist_off;     // slots of target tile tt: plist_off[tt] .. plist_off[tt + 1] - 1 (consecutive, engine.hip get_plan)
     int k, ks, HW, bits, words;   // ks: list slots per lane; bits: index bits of a packed maximum; words: bitmap words per target tile
     float* thr_grp;           // [TT*256]
@@ -392,20 +392,15 @@ __global__ __launch_bounds__(kTkSelCols * 64) void topk_select2_kernel(const Top
         const int nvals = (u1 - u0) * two_ks;
         const unsigned kfloor = sortable_key(-1.0e37f);      // "no group" fillers are not values
         const float dscale = __builtin_amdgcn_exp2f((float)(a.bits - 22));
-        // value v = 64 i + lane is entry (v % 2KS) of slot (v / 2KS): a cursor (slot, entry) that advances by 64 values per sweep
-        // step without a division
-        const int q64 = 64 / two_ks, r64 = 64 - q64 * two_ks;
-        const int sl0 = lane / two_ks, idx0 = lane - sl0 * two_ks;
-        int c_sl = sl0, c_idx = idx0;
-        auto rewind = [&]() { c_sl = sl0; c_idx = idx0; };
+        // the column's nvals list entries are contiguous: sweep step i reads entries 64 i .. 64 i + 63, one per lane
+        const float* colp = a.part + ((size_t)u0 * kBT + (size_t)tcol * (u1 - u0)) * two_ks;
+        int c_v = lane;
+        auto rewind = [&]() { c_v = lane; };
         auto next_key = [&]() -> unsigned {      // the cursor's value (0 past the end or for a filler), then advance.  The load
-            const bool in = c_sl < u1 - u0;      // itself is unconditional (clamped address): a run of them goes out back to back
-            const int sl = in ? c_sl : 0;
-            unsigned kk = sortable_key(a.part[((size_t)(u0 + sl) * kBT + tcol) * two_ks + c_idx]);
+            const bool in = c_v < nvals;         // itself is unconditional (clamped address): a run of them goes out back to back
+            unsigned kk = sortable_key(colp[in ? c_v : 0]);
             kk = in && kk > kfloor ? kk : 0u;
-            c_sl += q64;
-            c_idx += r64;
-            if (c_idx >= two_ks) { c_idx -= two_ks; ++c_sl; }
+            c_v += 64;
             return kk;
         };
         // the first kTkSelRegs sweep steps (64 values each) stay in registers - all of a column at the bench shapes - so sweep 2

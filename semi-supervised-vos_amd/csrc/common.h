@@ -94,6 +94,8 @@ struct PropArgs {
     int tk_k;                   // k of the top-k variant (pass 1 keeps KS = ceil(k / 8) * 8 list slots per lane)
     const float* tk_thr;        // [TT*256] pass 2: a group whose packed maximum reaches this holds candidates of the target pixel
     // [r3] top-k on the dense kernel's pipeline (prop_dense.h TK = 1 / 2, aux_kernels.h topk_select2 / topk_combine2)
+    const int* tk_off;          // [TT + 1] partial slots of target tile tt: tk_off[tt] .. tk_off[tt + 1] - 1 (pass 1 lays its lists out
+                                //   per target pixel: [tt][column][slot rank][half][KS])
     int tk_idx_bits;            // low mantissa bits of a packed group maximum that hold (stream index << 1 | half)
     unsigned* tk_bitmap;        // [TT][tk_words] one bit per reference tile (stream index): some column of the target tile has a
     int tk_words;               //   candidate group there; cleared by pass 1, marked by topk_select2_kernel, walked by pass 2

@@ -565,6 +565,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         lp.tk_part = ctx->tk_part;
         lp.dense_part = ctx->part;
         lp.dense_rows = 2 + d;
+        a.tk_off = plan->d_off;
         a.tk_idx_bits = bits;
         a.tk_bitmap = ctx->tk_bitmap;
         a.tk_words = words;

@@ -25,7 +25,7 @@
 
 #ifndef VOSPROP_DABLATE
 #define VOSPROP_DABLATE 0   // timing experiments only (tools/dense_ablate.sh; results are WRONG by construction): 1 = no softmax VALU in
-                            // the chain, 2 = no LDS fragment refills, 4 = no staging, 8 = no per-step barrier, 16 = no score MFMAs
+                            // the chain, 2 = no LDS fragment refills, 4 = no staging, 8 = no per-step barrier, 16 = no score MFMAs, 32 = no label MFMAs, 64 = no prior tiles
 #endif
 
 namespace vosprop {
@@ -471,7 +471,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 softmax_rows<PROB, FUSED>(Sp, Wt, c, mn * c, lt0, lt1, pk0, pk1);
             }
             if (NEED_L) st.l += lt0 + lt1;
+#if !(VOSPROP_DABLATE & 32)
             label_mfmas<LAB_LO>(labp, pk0, pk1, st.Y);
+#else
+            asm volatile("" : "+v"(pk0), "+v"(pk1));
+#endif
         };
 
         // TK 2: tile p-1's group of this lane is a candidate group of its column (its packed maximum x reaches the column's
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                     if (acc_row(r, h) >= rows_last) S[r] = kNegBig;
             }
             // the prior tile of tile p (used from the next step on; tile p-1 is finished)
-            if (!PROB && need_w) {
+            if (!PROB && need_w && !(VOSPROP_DABLATE & 64)) {
                 asm volatile("; prior tile" ::: "memory");
                 prior_tile<FUSED>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c,
                                   s_kq[sparse ? 1 : 0][tid] + (FUSED && TK == 0 ? st.m * c : 0.0f), Wt);      // (top-k: log2 w itself)
@@ -835,7 +839,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             continue;
         }
         if (TK == 1) {      // this segment's lists: 256 columns x (half, rank)
-            float* pl = A.part + (((size_t)part_slot * kBT + wave * kColsPerWave + j) * 2 + h) * KS;      // [slot][column][half][KS]
+            // lists of one target pixel are CONTIGUOUS: [target tile][column][slot rank][half][KS] (the select kernel streams them)
+            const int s_first = A.tk_off[tt], s_count = A.tk_off[tt + 1] - s_first;
+            float* pl = A.part + (((size_t)s_first * kBT + (size_t)(wave * kColsPerWave + j) * s_count + (part_slot - s_first)) * 2 + h) * KS;
 #pragma unroll
             for (int i = 0; i < KS; i += 4) *(f32x4*)(pl + i) = f32x4{tkv[i], tkv[i + 1], tkv[i + 2], tkv[i + 3]};
             continue;
