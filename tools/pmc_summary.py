@@ -24,7 +24,7 @@ for d in args.dirs:
         continue
     per = collections.defaultdict(lambda: collections.defaultdict(list))        # kernel -> counter -> [(dispatch id, value)]
     for r in csv.DictReader(open(fs[0])):
-        if 'prop_' in r['Kernel_Name']:
+        if 'prop_' in r['Kernel_Name'] or 'topk_select' in r['Kernel_Name']:      # what vosprop_time_last_propagation times
             per[short(r['Kernel_Name'])][r['Counter_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
     for kern, counters in sorted(per.items()):
         for k, v in sorted(counters.items()):
@@ -38,7 +38,7 @@ for d in args.dirs:
     if kt:
         ds = collections.defaultdict(list)
         for r in csv.DictReader(open(kt[0])):
-            if 'prop_' in r['Kernel_Name']:
+            if 'prop_' in r['Kernel_Name'] or 'topk_select' in r['Kernel_Name']:      # what vosprop_time_last_propagation times
                 ds[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
         for kern, v in sorted(ds.items()):
             v = v[-args.last:]
