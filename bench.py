@@ -68,7 +68,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha1()
     src = ROOT / 'semi-supervised-vos_amd' / 'csrc'
-    for name in sorted(p.name for p in src.glob('prop_*.h')) + ['common.h', 'aux_kernels.h']:
+    for name in sorted(p.name for p in src.glob('prop_*.h')) + ['common.h', 'aux_kernels.h', 'engine.hip']:
         h.update(name.encode())
         h.update((src / name).read_bytes())
     return h.hexdigest()[:12]
