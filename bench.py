@@ -362,10 +362,9 @@ def main():
     torch.manual_seed(0)
     net = vos_net.VOSNet(wl['model'])
     model_state = {k: v.clone() for k, v in net.state_dict().items()}
-    # the features leave the encoder as channels-last bf16 (one conversion pass over the batch inside the captured graph): the
-    # propagation kernel then reads the target frame in place and combine_kernel carries the ring copy - what the CLI does
-    net.prepare_for_inference(dev, enc_dtype, miopen_find=not args.no_miopen_find,
-                              feature_dtype=torch.bfloat16 if enc_dtype != torch.float32 else None)
+    # the features leave the encoder as channels-last f16 / bf16 and are handed over as they are: the propagation kernel reads the
+    # target frame in place (f16 -> bf16 as it is loaded) and combine_kernel carries the ring copy - what the CLI does
+    net.prepare_for_inference(dev, enc_dtype, miopen_find=not args.no_miopen_find)
     if not args.no_encoder_graph:
         net = vos_net.GraphedEncoder(net, max_graphs=8)     # the look-ahead batch forward as one HIP graph launch per shape
 
@@ -517,8 +516,9 @@ def main():
             'config': {'workload': args.workload, 'image': [H, W], 'feature_map': [Hd, Wd], 'ref_num': wl['ref_num'],
                        'frame_range': cfg['frame_range'], 'topk': wl['topk'], 'encoder': wl['model'],
                        'encoder_dtype': args.encoder_dtype,
-                       'feature_handoff': ('channels-last bf16 from the encoder graph, target frame read in place, ring copy inside '
-                                           'combine_kernel' if enc_dtype != torch.float32 and not wl['topk'] and not wl.get('materialise')
+                       'feature_handoff': (f'channels-last {args.encoder_dtype} as the encoder left it: target frame read in place (f16 '
+                                           'converted to bf16 in the kernel prologue), ring copy inside combine_kernel'
+                                           if enc_dtype != torch.float32 and not wl['topk'] and not wl.get('materialise')
                                            else 'push kernel into the ring per frame'),
                        'step_form': 'mask only (pred_out_dev = NULL)', 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},

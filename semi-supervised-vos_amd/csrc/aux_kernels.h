@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
                                                       float* __restrict__ pred, uint8_t* __restrict__ cls,
                                                       bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, int prob,
                                                       const UpArgs up, const uint4* __restrict__ cp_src,
-                                                      uint4* __restrict__ cp_dst, int cp_n, int no_l) {
+                                                      uint4* __restrict__ cp_dst, int cp_n, int no_l, int cp_f16) {
     __shared__ float red[4][kMaxClasses + 2][64];
     __shared__ float outv[kMaxClasses][64];
     __shared__ uint8_t clsv[64];
@@ -160,7 +160,19 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
     // -> ring slot; vosprop_step).  The propagation kernel read the target from the caller's buffer; the slot is first needed as a
     // REFERENCE by the next step.  This kernel is latency-bound (three dependent round trips), eight independent 16-byte copies per
     // thread in front of them cost nothing and save the separate copy launch and its dispatch gap.
-    for (int i = blockIdx.x * 256 + tid; i < cp_n; i += gridDim.x * 256) cp_dst[i] = cp_src[i];
+    // [r3] cp_f16: the caller's features are f16 - converted on the way (what push_hwc_kernel would have done up front)
+    for (int i = blockIdx.x * 256 + tid; i < cp_n; i += gridDim.x * 256) {
+        uint4 v = cp_src[i];
+        if (cp_f16) {
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+            const f16x8 hv = __builtin_bit_cast(f16x8, v);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(float)hv[e];
+            v = __builtin_bit_cast(uint4, o);
+        }
+        cp_dst[i] = v;
+    }
     const int t = blockIdx.x * 64 + col;
     const int tt = (blockIdx.x * 64) / kBT, tcol = (blockIdx.x * 64) % kBT + col;
     const size_t ustride = (size_t)(2 + d) * kBT;

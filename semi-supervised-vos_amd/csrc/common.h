@@ -82,6 +82,7 @@ struct PropArgs {
     int target_slot;
     const bf16_t* target_feat;  // dense bf16 kernel: the target frame's features [target_rows][kC] - its ring slot, or the caller's own
     int target_rows;            // channels-last bf16 buffer (HW rows) when the ring copy rides in combine_kernel (engine.hip vosprop_step)
+    int target_f16;             // [r3] the caller's buffer holds f16 (an f16 encoder's output): converted to bf16 as it is loaded
     int n_ref;
     int HW, HWp, Wd;
     int d;

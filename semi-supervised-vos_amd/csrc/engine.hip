@@ -113,6 +113,7 @@ struct vosprop_ctx {
     uint8_t* fuse_mask = nullptr;  // set by vosprop_step around propagate(): the mask combine_kernel should write
     unsigned tseq = 0;                 // eligible launches seen since vosprop_timing_begin
     bool mask_only = false;            // set by vosprop_step around propagate(): the caller did not ask for the prediction
+    bool fuse_f16 = false;             // ... and they are f16 (converted where they are read)
     const void* fuse_push = nullptr;   // set by vosprop_step around propagate(): channels-last bf16 features of the target frame that
                                        // the propagation reads in place and combine_kernel copies into the target's ring slot
     LastProp last;
@@ -499,6 +500,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     bf16_t* const target_in_ring = ring.feat ? ring.feat + (size_t)target_slot * ctx->HWp * kC : nullptr;
     a.target_feat = ctx->fuse_push ? (const bf16_t*)ctx->fuse_push : target_in_ring;
     a.target_rows = ctx->fuse_push ? ctx->HW : ctx->HWp;
+    a.target_f16 = ctx->fuse_push && ctx->fuse_f16 ? 1 : 0;
     a.n_ref = n_ref;
     a.HW = ctx->HW;
     a.HWp = ctx->HWp;
@@ -649,11 +651,12 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         const int cp_n = ctx->fuse_push ? (int)((size_t)ctx->HW * kC * sizeof(bf16_t) / 16) : 0;
         hipLaunchKernelGGL(combine_kernel, cgrid, dim3(256), 0, s, ctx->part, plan->d_off, plan->d_list, d, ctx->HW, a.c, pred,
                            cls, new_lab_hi, new_lab_lo, prob ? 1 : 0, up, (const uint4*)ctx->fuse_push, (uint4*)target_in_ring, cp_n,
-                           lp.no_l ? 1 : 0);
+                           lp.no_l ? 1 : 0, ctx->fuse_push && ctx->fuse_f16 ? 1 : 0);
         // re-runs of this propagation (vosprop_time_last_propagation, debug hooks) read the target from the ring: the caller's
         // buffer is only promised until the work enqueued by this call has run
         a.target_feat = target_in_ring;
         a.target_rows = ctx->HWp;
+        a.target_f16 = 0;
     }
     HIP_TRY(ctx, hipGetLastError());
 #ifdef VOSPROP_STAMP
@@ -1067,7 +1070,8 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     // target frame where the encoder left it and combine_kernel carries the copy (one launch and one dispatch gap fewer per frame)
     static const bool no_fuse_push = getenv("VOSPROP_FUSE_PUSH") && atoi(getenv("VOSPROP_FUSE_PUSH")) == 0;
     static const bool two_burst_env = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
-    const bool fuse_push = f > 0 && feat_dtype == (VOSPROP_DT_BF16 | VOSPROP_LAYOUT_HWC) && ctx->cfg.precision == VOSPROP_PREC_BF16 &&
+    const bool hwc16 = feat_dtype == (VOSPROP_DT_BF16 | VOSPROP_LAYOUT_HWC) || feat_dtype == (VOSPROP_DT_F16 | VOSPROP_LAYOUT_HWC);
+    const bool fuse_push = f > 0 && hwc16 && ctx->cfg.precision == VOSPROP_PREC_BF16 &&
                            ctx->cfg.topk == 0 && !ctx->cfg.materialise && !no_fuse_push && !two_burst_env;
     int rc = fuse_push ? VOSPROP_OK : push_features(ctx, feat_dev, feat_dtype, R, slot, s);
     if (rc) return rc;
@@ -1086,6 +1090,7 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     const bool fuse_up = mask_out_dev && ctx->cfg.topk == 0;      // dense path: combine_kernel writes the mask itself
     ctx->fuse_mask = fuse_up ? mask_out_dev : nullptr;
     ctx->fuse_push = fuse_push ? feat_dev : nullptr;
+    ctx->fuse_f16 = fuse_push && feat_dtype == (VOSPROP_DT_F16 | VOSPROP_LAYOUT_HWC);
     ctx->mask_only = pred_out_dev == nullptr;
     rc = propagate(ctx, R, slots, n_ref, f, slot, ctx->d, prob, prob, ctx->cfg.sigma1, ctx->cfg.sigma2,
                    ctx->cfg.temperature, ctx->pred_buf, cls_slot, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s);

@@ -399,6 +399,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(Bt[ks]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (A.target_f16) {      // an f16 encoder's features, read where it left them: the same round-to-nearest-even conversion the
+                                 // push kernel would have done on the way into the ring (wave-uniform; once per segment)
+            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const f16x8 hv = __builtin_bit_cast(f16x8, Bt[ks]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Bt[ks][e] = (bf16_t)(float)hv[e];
+            }
+        }
 #ifdef VOSPROP_STAMP
         STAMP_AT(14);   // 14: wait for all of it
 #endif

@@ -152,8 +152,9 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
     net = VOSNet(model=model)
     net = load_model(net, resume)
     dtype = _DTYPES[encoder_dtype] if Config.DEVICE.type == 'cuda' else None
-    # an f16 / bf16 encoder hands its features to the bf16 propagation path as bf16 (read in place, no push launch per frame)
-    fdt = torch.bfloat16 if (dtype is not None and propagation_precision == 'bf16') else None
+    # an f16 / bf16 encoder hands its channels-last features over as they are: the propagation kernel reads the target frame in
+    # place (f16 is converted to bf16 as it is loaded) and combine_kernel carries the ring copy - no push launch per frame
+    fdt = None
     net.prepare_for_inference(Config.DEVICE, dtype, miopen_find=miopen_find, feature_dtype=fdt)
     additional = None
     if inference_strategy == 'multimodel':      # reference src/inference.py:65-71

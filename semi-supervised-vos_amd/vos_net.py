@@ -267,10 +267,8 @@ class VOSNet(nn.Module):
         bench.py), but the search costs 10-20 s per new batch shape in every process (it is not cached across processes on this
         stack), more than a whole DAVIS-sized job takes: off by default, on in bench.py (search in the untimed warm-up) and
         with `main.py inference --miopen-find` for long jobs.  feature_dtype (fused path only): the features leave the encoder in
-        this type - torch.bfloat16 for an f16 encoder feeding the bf16 propagation path: the engine's ring is bf16 either way
-        (the same round-to-nearest-even conversion its push kernel would do per frame), but bf16 channels-last features are read
-        IN PLACE by the propagation kernel (vosprop_step: no push launch per frame), and converting the whole look-ahead batch is
-        one pass inside the captured graph (~1 us per 480p frame)."""
+        this type (one element-wise pass over the batch inside the captured graph, 3.8 us per 480p frame measured).  Not used by
+        the CLI or the bench any more: the engine reads channels-last f16 as well as bf16 features in place (vosprop_step)."""
         self.feature_dtype = feature_dtype
         if miopen_find and torch.device(device).type == 'cuda':
             torch.backends.cudnn.benchmark = True
