@@ -434,3 +434,36 @@ def test_work_plan_covers_every_unit_once(vos, TT, NT, streamk):
             if b % 8 == 0 and b not in first:
                 first[b] = (r_lo, ns)
         assert len(set(first.values())) == 1
+
+
+def test_no_compiler_generated_m0_reader_in_the_propagation_kernels(tmp_path):
+    """glds16s / glds16s2 (csrc/prop_bf16.h) set M0 inside an asm statement and do not restore it (M0 is a reserved register: it
+    cannot be put on a clobber list).  That is only sound while hipcc itself emits nothing that READS M0 in those kernels
+    (v_movrel / s_movrel indirect indexing, s_sendmsg, GDS ops, its own `... lds` loads): this test compiles the engine to ISA and
+    fails if any line of a propagation kernel mentions m0 outside the three forms the asm statements themselves produce."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not Path(hipcc).exists():
+        pytest.skip('no hipcc')
+    src = ROOT / 'semi-supervised-vos_amd' / 'csrc'
+    out = tmp_path / 'engine.s'
+    subprocess.run([hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fno-slp-vectorize', '-S', '--cuda-device-only', '-o',
+                    str(out), 'engine.hip'], cwd=src, check=True, capture_output=True, timeout=600)
+    text = out.read_text()
+    ours = (re.compile(r'^\s*s_add_u32 m0, \S+, \S+\s*$'), re.compile(r'^\s*s_mov_b32 m0, \S+\s*$'),
+            re.compile(r'^\s*s_mov_b32 \S+, m0\s*$'))
+    kernel, bad, seen = None, [], 0
+    for ln in text.splitlines():
+        m = re.match(r'^(_ZN7vosprop\w+):', ln)
+        if m:
+            kernel = m.group(1)
+        if kernel and ('prop_dense_kernel' in kernel or 'prop_bf16_kernel' in kernel):
+            code = ln.split(';')[0]
+            if re.search(r'\bm0\b', code):
+                seen += 1
+                if not any(p.match(code) for p in ours):
+                    bad.append((kernel[:60], code.strip()))
+    assert seen > 0, 'no LDS-DMA piece found: the check is not looking at the right kernels'
+    assert not bad, bad[:5]

@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/r03
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-PARTS=" ${R03_PARTS:-1 3 4} "
+PARTS=" ${R03_PARTS:-1 3 4 5 6 7 8} "
 # 1. kernel stats of the default bench command
 if [[ "$PARTS" == *" 1 "* ]]; then
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -- python $R/bench.py > $O/bench_under_rocprofv3.json 2> $O/bench_prof.err || echo "bench profile failed"
@@ -31,5 +31,56 @@ bash tools/pmc.sh r03 "" --stateful > $O/pmc.log 2>&1
 cp gpurun_out/pmc_r03_summary.txt $O/prop_kernel_pmc.txt
 bash tools/pmc.sh r03topk "" --stateful --ref-num 5 --topk 20 > $O/pmc_topk.log 2>&1
 cp gpurun_out/pmc_r03topk_summary.txt $O/topk_kernels_pmc.txt
+fi
+# 5. which encoder kernels are reproducible (tools/determinism_probe.py), with the kernel names of both modes
+if [[ "$PARTS" == *" 5 "* ]]; then
+cd /tmp
+export VOSPROP_CACHE_DIR=/tmp/vpc_det && mkdir -p $VOSPROP_CACHE_DIR
+{
+for m in nondet det; do F=""; [ $m = det ] && F="--det"
+  echo "==== resnet18 f16 96x160 batch 32, $m, process 1 / 2 (digests must agree between processes in deterministic mode)"
+  python3 $R/tools/determinism_probe.py --model resnet18 --size 96 160 --batch 32 --frames 9 $F 2>&1 | grep -v amdgpu.ids
+  python3 $R/tools/determinism_probe.py --model resnet18 --size 96 160 --batch 32 --frames 9 $F 2>&1 | grep -E "digest|run-to-run"
+  echo "==== resnet50 f16 480x854 batch 8, $m"
+  python3 $R/tools/determinism_probe.py --model resnet50 --size 480 854 --batch 8 --frames 3 $F 2>&1 | grep -v amdgpu.ids
+  python3 $R/tools/determinism_probe.py --model resnet50 --size 480 854 --batch 8 --frames 3 $F 2>&1 | grep -E "digest|run-to-run"
+  rm -rf /tmp/detprof_$m
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/detprof_$m -- python3 $R/tools/determinism_probe.py --model resnet18 --size 96 160 --batch 32 --frames 9 --repeats 1 $F > /dev/null 2>&1
+  echo "==== convolution kernels of the resnet18 run, $m (rocprofv3 kernel stats: name, calls, average ns)"
+  python3 - "$(find /tmp/detprof_$m -name '*kernel_stats.csv' | head -1)" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r['Name']
+    if any(k in n.lower() for k in ('igemm', 'conv', 'gemm', 'cijk', 'winograd', 'naive', 'implicit')):
+        print(f"   {r['Calls']:>5s} calls {float(r['AverageNs']) / 1e3:9.1f} us  {n[:150]}")
+PY
+done
+} > $O/determinism_probe.txt 2>&1
+echo "determinism done"
+cd $R
+fi
+# 6. bench lines of the other workloads
+if [[ "$PARTS" == *" 6 "* ]]; then
+: > $O/bench_other_workloads.jsonl
+for wl in ytvos720p_r50_dense davis480p_r50_top20_ref5 pair240p_r18 ytvos720p_r50_dense_materialised; do
+  timeout -k 10 400 python $R/bench.py --no-cpu-baseline --no-end-to-end --workload $wl >> $O/bench_other_workloads.jsonl 2>> $O/bench_other.err || echo "bench $wl failed"
+done
+timeout -k 10 300 python $R/bench.py --steps 20 --warmup 5 > $O/bench_driver_form.json 2>> $O/bench_other.err || echo "driver-form bench failed"
+echo "other workloads done"
+fi
+# 7. dense kernel: ablations and stamps
+if [[ "$PARTS" == *" 7 "* ]]; then
+bash tools/dense_ablate.sh "0 1 2 4 16 32 64 23 119" 2>&1 | grep "dense ablate" | cut -c1-70 > $O/dense_kernel_ablations.txt
+bash tools/stamp.sh --stateful 2>&1 | tail -9 > $O/dense_kernel_stamps.txt
+echo "ablations done"
+fi
+# 8. the real command line, host to host, with and without --deterministic
+if [[ "$PARTS" == *" 8 "* ]]; then
+{
+python tools/cli_bench.py --videos 16 --frames 128 --io-workers 8 8 8 --png-workers 2
+python tools/cli_bench.py --videos 16 --frames 128 --io-workers 8 8 --png-workers 2 --extra=--deterministic
+python tools/cli_bench.py --videos 48 --frames 128 --io-workers 8 --png-workers 2
+} > $O/cli_end_to_end.txt 2>&1
+echo "cli done"
 fi
 echo "all done"
