@@ -148,7 +148,7 @@ def mask_parity(wl, cfg, ann, feats, gpu_masks, n_frames=7):
     iou = vo.mask_iou_per_object(want, got, d)
     return {'frames': n - 1, 'pixels_differing': float(np.mean(got != want)), 'per_object_iou': [round(v, 5) for v in iou],
             'iou_delta': round(1.0 - min(iou), 5),
-            'what': 'engine masks vs oracle (torch-CPU restatement of the reference) on identical bf16 encoder features'}
+            'what': 'engine masks (mask-only steps, the timed kernel form) vs oracle (torch-CPU restatement of the reference) on the same encoder features'}
 
 
 def end_to_end_leg(args, wl, dev, clip, pool, net, eng, enc_dtype, fence, world, on_gloo):
@@ -524,7 +524,7 @@ def main():
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
             'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us, 'end_to_end': end_to_end,
             'roofline': {'kernel': ('prop_dense_kernel<.,.,1> + <.,.,2> (affinity out to HBM, then back)' if hbm_bound else
-                                    'prop_bf16_kernel<.,.,1> + <.,.,2> (top-k passes)' if wl['topk'] else 'prop_dense_kernel'),
+                                    'prop_dense_kernel<TK=1> + topk_select2_kernel + prop_dense_kernel<TK=2> (one scoring pass, select, re-score of the marked tiles)' if wl['topk'] else 'prop_dense_kernel<mask-only form>'),
                          'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': achieved_gbs if hbm_bound else achieved,
                          'peak': HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TFLOPS, 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                          'frac': achieved_gbs / HBM_PEAK_GBS if hbm_bound else achieved / MFMA_BF16_PEAK_TFLOPS,
