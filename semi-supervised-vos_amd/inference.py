@@ -85,19 +85,61 @@ def inference_command(ref_num, data, resume, model, temperature, frame_range, si
                            propagation_precision=propagation_precision, deterministic=deterministic)
 
 
-def set_deterministic(on=True):
-    """Process-wide reproducible mode of the encoder (measured with tools/determinism_probe.py):
-      * torch.backends.cudnn.deterministic -> MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC on every convolution descriptor: MIOpen leaves
-        out the solvers that split the reduction over workgroups and accumulate with atomics (the f16 3x3 convolutions of small
-        maps: 10-24 % of their outputs differ from one launch to the next without it);
+# MIOpen solver families that are switched OFF in reproducible mode (environment variables read by MIOpen when it looks for a
+# solver): the assembly implicit-GEMM family for NHWC forward convolutions is the one whose small-map kernels (`igemm_fwd_gtcx35_nhwc_
+# ..._gkgs`: "gemm-k global split") split the reduction over workgroups and accumulate with atomics (tools/determinism_probe.py:
+# 11-24 % of a 3x3 convolution's f16 outputs change from one launch to the next).
+_MIOPEN_NONDETERMINISTIC_SOLVERS = ('MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC',)
+
+
+# The split-K kernels are MIOpen's choice for SMALL problems only (too few output tiles to fill 256 CUs: 12x20 maps at batch 32 =
+# 60 tiles); at >= this many stride-8 output pixels per encoder batch (480p at batch 32: 205 440) the family's kernels are the
+# plain ones and reproducible (probe), and they are 7x faster than what the library falls back to without the family (a slow CK
+# instance in immediate mode: 2.5 ms instead of 0.36 ms per 480p frame).  So the family is only switched off below the threshold -
+# and whatever was decided, the CLI CHECKS the encoder for reproducibility before it trusts it (encoder_is_reproducible).
+_SPLIT_K_PIXELS = 131072
+
+
+def set_deterministic(on=True, pixels_per_batch=None):
+    """Process-wide reproducible mode of the encoder (measured with tools/determinism_probe.py).  Call it
+    before the first convolution of the process (the CLI does, first thing).  pixels_per_batch: encoder batch x ceil(H/8) x
+    ceil(W/8) of the job (None = unknown: the safe, slow choice).
+      * MIOpen: for small problems the solver family with atomic split-K kernels is disabled through its environment switch (read
+        once by the library, hence "before the first convolution"), so the library picks its next choice - which is reproducible
+        on this stack (the probe checks every convolution call bitwise).  NOT `torch.backends.cudnn.deterministic`: that sets
+        MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC, and this MIOpen then falls back to its naive reference kernel
+        (`naive_conv_ab_nonpacked_fwd_nhwc`, 6.6 ms per call at 12x20 maps: `main.py inference` at 480p ran at 6 frames/s
+        instead of 820 - correct, useless);
+      * a timed solver search (--miopen-find) is a race between solvers: off;
       * vosprop_set_deterministic: the pointwise-GEMM algorithm of a layer is the first gated candidate in the library's rank
         order - no timing race between candidates, no cache file - so every process picks the same kernel.
-    The propagation kernels need nothing: fixed work map, partials merged in a fixed order, no atomics on the dense path."""
+    The propagation kernels need nothing: fixed work map, partials merged in a fixed order, no atomics on values."""
     from . import _native
-    torch.backends.cudnn.deterministic = bool(on)
+    small = pixels_per_batch is None or pixels_per_batch < _SPLIT_K_PIXELS
+    for name in _MIOPEN_NONDETERMINISTIC_SOLVERS:
+        if on and small:
+            os.environ[name] = '0'
+        else:
+            os.environ.pop(name, None)
     if on:
         torch.backends.cudnn.benchmark = False
     _native.lib().vosprop_set_deterministic(1 if on else 0)
+
+
+def encoder_is_reproducible(net, shape, dtype, device, repeats=2):
+    """Encode the same random batch `repeats` + 1 times and compare the features bitwise (the deterministic mode's self-check: a
+    library update or an unusual frame size must not silently bring an atomic-accumulate kernel back)."""
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = torch.randn(shape, generator=g).to(device)
+    if dtype is not None:
+        x = x.to(dtype)
+    x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        net(x)                                   # warm: solver look-ups, GEMM plans
+        ref = net(x).clone()
+        same = all(torch.equal(net(x), ref) for _ in range(repeats))
+    torch.cuda.synchronize()
+    return same
 
 
 def visible_devices(n):
@@ -143,7 +185,15 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
                            png_workers=2, encoder_graph=True, miopen_find=False, propagation_precision='bf16',
                            deterministic=False):
     if deterministic:
-        set_deterministic(True)
+        # before the first convolution of the process: the job's frame size decides which MIOpen solvers are allowed
+        first = next(iter(list_videos(str(Path(data) / 'JPEGImages/480p')).values()), None)
+        det_shape = None
+        if first:
+            from PIL import Image
+            with Image.open(first[0]) as im0:
+                w0, h0 = im0.size
+            det_shape = (max(1, encoder_batch), 3, h0, w0)
+        set_deterministic(True, None if det_shape is None else det_shape[0] * -(-h0 // 8) * -(-w0 // 8))
         miopen_find = False        # a timed solver search is a race between solvers: its winner can differ from process to process
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)
@@ -163,6 +213,12 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
         additional = load_model(VOSNet(model=additional_model_type), additional_resume)
         additional.prepare_for_inference(Config.DEVICE, dtype, miopen_find=miopen_find, feature_dtype=fdt)
 
+    if deterministic and Config.DEVICE.type == 'cuda' and det_shape is not None and inference_strategy in ('single', 'multimodel'):
+        for enc in [net] + ([additional] if additional is not None else []):
+            if not encoder_is_reproducible(enc, det_shape, dtype, Config.DEVICE):
+                raise click.ClickException('--deterministic: the encoder is NOT bit-reproducible for input '
+                                           f'{det_shape} on this software stack (a library kernel accumulates with atomics); '
+                                           'see DESIGN.md section 7.1 / tools/determinism_probe.py')
     if Config.DEVICE.type == 'cuda' and encoder_graph:
         # full batches of one resolution replay a captured HIP graph; everything else (last batch of a video, another
         # resolution) runs the eager module

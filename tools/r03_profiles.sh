@@ -32,29 +32,36 @@ cp gpurun_out/pmc_r03_summary.txt $O/prop_kernel_pmc.txt
 bash tools/pmc.sh r03topk "" --stateful --ref-num 5 --topk 20 > $O/pmc_topk.log 2>&1
 cp gpurun_out/pmc_r03topk_summary.txt $O/topk_kernels_pmc.txt
 fi
-# 5. which encoder kernels are reproducible (tools/determinism_probe.py), with the kernel names of both modes
+# 5. which encoder kernels are reproducible (tools/determinism_probe.py), with the convolution kernel names of each mode
 if [[ "$PARTS" == *" 5 "* ]]; then
 cd /tmp
 export VOSPROP_CACHE_DIR=/tmp/vpc_det && mkdir -p $VOSPROP_CACHE_DIR
-{
-for m in nondet det; do F=""; [ $m = det ] && F="--det"
-  echo "==== resnet18 f16 96x160 batch 32, $m, process 1 / 2 (digests must agree between processes in deterministic mode)"
-  python3 $R/tools/determinism_probe.py --model resnet18 --size 96 160 --batch 32 --frames 9 $F 2>&1 | grep -v amdgpu.ids
-  python3 $R/tools/determinism_probe.py --model resnet18 --size 96 160 --batch 32 --frames 9 $F 2>&1 | grep -E "digest|run-to-run"
-  echo "==== resnet50 f16 480x854 batch 8, $m"
-  python3 $R/tools/determinism_probe.py --model resnet50 --size 480 854 --batch 8 --frames 3 $F 2>&1 | grep -v amdgpu.ids
-  python3 $R/tools/determinism_probe.py --model resnet50 --size 480 854 --batch 8 --frames 3 $F 2>&1 | grep -E "digest|run-to-run"
-  rm -rf /tmp/detprof_$m
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/detprof_$m -- python3 $R/tools/determinism_probe.py --model resnet18 --size 96 160 --batch 32 --frames 9 --repeats 1 $F > /dev/null 2>&1
-  echo "==== convolution kernels of the resnet18 run, $m (rocprofv3 kernel stats: name, calls, average ns)"
-  python3 - "$(find /tmp/detprof_$m -name '*kernel_stats.csv' | head -1)" <<'PY'
+probe() { python3 $R/tools/determinism_probe.py "$@" 2>&1 | grep -v amdgpu.ids; }
+kernels() {   # convolution kernels of one probe run: calls, average us, name
+  rm -rf /tmp/detprof; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/detprof -- python3 $R/tools/determinism_probe.py "$@" --repeats 1 > /dev/null 2>&1
+  python3 - "$(find /tmp/detprof -name '*kernel_stats.csv' | head -1)" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r['Name']
-    if any(k in n.lower() for k in ('igemm', 'conv', 'gemm', 'cijk', 'winograd', 'naive', 'implicit')):
-        print(f"   {r['Calls']:>5s} calls {float(r['AverageNs']) / 1e3:9.1f} us  {n[:150]}")
+    if any(k in n.lower() for k in ('igemm', 'conv', 'winograd', 'naive', 'implicit')) and 'pw_' not in n:
+        print(f"   {r['Calls']:>5s} calls {float(r['AverageNs']) / 1e3:9.1f} us  {n[:140]}")
 PY
-done
+}
+{
+small="--model resnet18 --size 96 160 --batch 32 --frames 9"
+big="--model resnet50 --size 480 854 --batch 32 --frames 12 --repeats 2"
+echo "==== A. the failing test's shapes (resnet18 f16, 96x160 frames, batch 32), library defaults: process 1, then the digest line of process 2"
+probe $small; probe $small | grep -E "digest|run-to-run"
+echo "==== A. convolution kernels (rocprofv3 kernel stats)"; kernels $small
+echo "==== B. same shapes, inference.set_deterministic() (this size: MIOpen's ASM implicit-GEMM NHWC family switched off): process 1 / 2"
+probe $small --det; probe $small --det | grep -E "digest|run-to-run"
+echo "==== B. convolution kernels"; kernels $small --det
+echo "==== C. same shapes, torch.backends.cudnn.deterministic instead (MIOPEN_CONVOLUTION_ATTRIB_DETERMINISTIC): reproducible, naive kernel"
+probe $small --cudnn-det | grep -E "run-to-run|digest"
+echo "==== C. convolution kernels"; kernels $small --cudnn-det
+echo "==== D. the bench / CLI shape (resnet50 f16, 480x854, batch 32), library defaults = what set_deterministic() keeps at this size: process 1 / 2"
+probe $big; probe $big | grep -E "digest|run-to-run"
+echo "==== D. convolution kernels"; kernels $big
 } > $O/determinism_probe.txt 2>&1
 echo "determinism done"
 cd $R
@@ -77,9 +84,9 @@ fi
 # 8. the real command line, host to host, with and without --deterministic
 if [[ "$PARTS" == *" 8 "* ]]; then
 {
-python tools/cli_bench.py --videos 16 --frames 128 --io-workers 8 8 8 --png-workers 2
-python tools/cli_bench.py --videos 16 --frames 128 --io-workers 8 8 --png-workers 2 --extra=--deterministic
-python tools/cli_bench.py --videos 48 --frames 128 --io-workers 8 --png-workers 2
+timeout -k 10 300 python tools/cli_bench.py --videos 16 --frames 128 --io-workers 8 8 8 --png-workers 2
+timeout -k 10 300 python tools/cli_bench.py --videos 16 --frames 128 --io-workers 8 8 --png-workers 2 --extra=--deterministic
+timeout -k 10 300 python tools/cli_bench.py --videos 48 --frames 128 --io-workers 8 --png-workers 2
 } > $O/cli_end_to_end.txt 2>&1
 echo "cli done"
 fi
