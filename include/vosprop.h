@@ -70,7 +70,8 @@ typedef struct vosprop_config {
     float temperature;    /* --temperature  (src/inference.py:26), default 1; must be > 0        */
     int probability;      /* --probability  (src/inference.py:42): 0 = propagate one-hot labels  */
     int topk;             /* 0 = dense (the reference); 1..32 = keep the k largest A[.,t] per target pixel, zero the rest,
-                             no renormalisation (NOT in the reference; label-propagation mode only; two kernel passes) */
+                             no renormalisation (NOT in the reference; label-propagation mode only; one scoring pass + a re-score
+                             of the reference tiles that can hold a kept entry; at most 32 768 reference tiles per step) */
     int precision;        /* VOSPROP_PREC_*                                                      */
     int ring_capacity;    /* 0 = auto: max(frame_range + 4, ref_num) + 1 frames; anything smaller is VOSPROP_E_INVALID */
     int materialise;      /* 0 = fused (nothing of size (H_d W_d)^2 touches HBM).  1 = the reference's algorithm SHAPE

@@ -467,3 +467,30 @@ def test_no_compiler_generated_m0_reader_in_the_propagation_kernels(tmp_path):
                     bad.append((kernel[:60], code.strip()))
     assert seen > 0, 'no LDS-DMA piece found: the check is not looking at the right kernels'
     assert not bad, bad[:5]
+
+
+def test_set_deterministic_switches_the_library_and_the_solver_family(monkeypatch):
+    """inference.set_deterministic: small problems switch MIOpen's atomic split-K solver family off through its environment switch
+    (read by the library before its first convolution), large ones keep the library's defaults; the pointwise-GEMM tuner's flag
+    (vosprop_set_deterministic, process-wide) follows and reports its previous state.  No GPU needed: nothing is launched."""
+    import os
+    inf = importlib.import_module('semi-supervised-vos_amd.inference')
+    native = importlib.import_module('semi-supervised-vos_amd._native')
+    name = inf._MIOPEN_NONDETERMINISTIC_SOLVERS[0]
+    monkeypatch.delenv(name, raising=False)
+    native.lib().vosprop_set_deterministic(0)
+    try:
+        inf.set_deterministic(True, pixels_per_batch=32 * 12 * 20)          # the failing round-2 test's size
+        assert os.environ.get(name) == '0'
+        assert native.lib().vosprop_set_deterministic(1) == 1
+        inf.set_deterministic(True, pixels_per_batch=32 * 60 * 107)         # 480p at the CLI's batch: defaults stay
+        assert name not in os.environ
+        inf.set_deterministic(True)                                         # unknown size: the safe choice
+        assert os.environ.get(name) == '0'
+        inf.set_deterministic(False)
+        assert name not in os.environ and native.lib().vosprop_set_deterministic(0) == 0
+    finally:
+        os.environ.pop(name, None)
+        native.lib().vosprop_set_deterministic(0)
+        import torch
+        torch.backends.cudnn.benchmark = False
