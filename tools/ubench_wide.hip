@@ -194,5 +194,10 @@ int main() {
     run<0, 0, 4, 5, 1>("X + cursor: 20 scalar instructions, 4 per gap in gaps 0-4");
     run<0, 0, 8>("X + alarm compare and branch");
     run<0, 0, 31>("X + all");
+    run<0, 0, 31, 10, 1>("X + all, the 40 scalar instructions 4 per gap");
+    run<0, 0, 31, 5, 0>("X + all, 20 scalar instructions behind the chain");
+    run<0, 0, 31, 5, 1>("X + all, 20 scalar instructions 4 per gap");
+    run<0, 0, 11>("X + all but the cursor");
+    run<0, 0, 30>("X + all but staging");
     return 0;
 }
