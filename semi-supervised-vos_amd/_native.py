@@ -67,7 +67,7 @@ SYMBOLS = {
 
 # -fno-slp-vectorize: packed f32 VALU instructions do not overlap with MFMAs on gfx950 (tools/ubench_slot.hip); without the
 # flag hipcc packs the softmax sums into v_pk_add_f32 and the shipped kernel is 5 % slower (measured)
-HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize']
+HIPCC_FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 # hipBLASLt serves the encoder's pointwise convolutions (csrc/pointwise.h); in a torch process the copy torch has already loaded
 # (same SONAME) is the one that binds
 LINK_FLAGS = ['-L/opt/rocm/lib', '-lhipblaslt', '-Wl,-rpath,/opt/rocm/lib']

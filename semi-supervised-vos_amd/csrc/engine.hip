@@ -18,6 +18,7 @@
 #include "common.h"
 #include "prop_bf16.h"
 #include "prop_dense.h"
+#include "prop_wide.h"
 #include "prop_f32.h"
 #include "pointwise.h"
 #include "encoder_ops.h"
@@ -401,6 +402,7 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
     // dense path: the in-wave pipelined kernel (prop_dense.h).  VOSPROP_DENSE_TWO_BURST=1 selects the round-1 two-burst schedule of
     // prop_bf16.h (same results; A/B timing only)
     static const bool two_burst = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
+    static const bool wide = getenv("VOSPROP_WIDE") ? atoi(getenv("VOSPROP_WIDE")) != 0 : false;
     if (lp.materialise) {   // the materialised-affinity variant: score tiles out to HBM, then back in (prop_dense.h MAT 1 / 2)
         if (lp.prob) {
             hipLaunchKernelGGL((prop_dense_kernel<true, true, 1>), grid, block, 0, s, a);
@@ -418,7 +420,11 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
             else hipLaunchKernelGGL((prop_dense_kernel<true, false>), grid, block, 0, s, a);
         } else {
             if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<false, true>), grid, block, 0, s, a);
-            else if (lp.no_l) {
+            else if (lp.no_l && wide) {      // the mask-only form in its four-wave shape (prop_wide.h)
+                const dim3 wblock(kWavesW * 64);
+                if (e0) hipExtLaunchKernelGGL(prop_wide_kernel, grid, wblock, 0, s, e0, e1, 0, a);
+                else hipLaunchKernelGGL(prop_wide_kernel, grid, wblock, 0, s, a);
+            } else if (lp.no_l) {
                 if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false, 0, false>), grid, block, 0, s, e0, e1, 0, a);
                 else hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false>), grid, block, 0, s, a);
             } else if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, e0, e1, 0, a);

@@ -133,18 +133,57 @@ __global__ __launch_bounds__(SHAPE == 0 ? 512 : 256) void k(float* out, int iter
                 ROW(P0, ks, pk0);
                 MFMA(S1, a[(ks + 1) & 7], b2);      // (the same fragment in the real kernel; another register here keeps the asm simple)
                 ROW(P1, ks, pk1);
+                if ((F & 1) && ks % 3 == 1) {      // all four waves stage: pieces 0..4 in gaps 1, 4, 7, 10, 13
+                    unsigned vtmp;
+                    asm volatile("s_add_u32 m0, %3, %4\n\tv_add_u32 %0, %1, %2\n\tglobal_load_lds_dwordx4 %0, %5"
+                                 : "=&v"(vtmp)
+                                 : "v"(lane_off), "s"(src_off + (unsigned)(ks / 3) * 4096u), "s"(smem_base + stg), "s"((unsigned)(wave + 4 * (ks / 3)) * 1024u), "s"(ring)
+                                 : "memory", "scc");
+                }
+                if ((F & 4) && INGAP && ks < NS) {
+                    asm volatile("s_add_i32 %0, %0, 1\n\ts_cmp_eq_u32 %0, %2\n\ts_cselect_b32 %0, 0, %0\n\ts_addc_u32 %1, %1, 0"
+                                 : "+s"(cur_a), "+s"(cur_b) : "s"(9 + ks) : "scc");
+                }
+                if ((F & 2) && ks == 10) {
+                    asm volatile("ds_read_b128 %0, %2 offset:17408\n\tds_read_b128 %1, %2 offset:18432" : "=v"(lab), "=v"(lab2) : "v"(smem_base + prv + lane * 16));
+                }
                 if (LAB_IN_CHAIN && ks == 8) { pkA = f32x4{pk0[0], pk0[1], pk0[2], pk0[3]}; pkC = f32x4{pk1[0], pk1[1], pk1[2], pk1[3]}; MFMA(Y0, lab, pkA); }
                 if (LAB_IN_CHAIN && ks == 9) MFMA(Y1, lab, pkC);
                 if (ks >= 8) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
             }
             pkB = f32x4{pk0[4], pk0[5], pk0[6], pk0[7]}; pkD = f32x4{pk1[4], pk1[5], pk1[6], pk1[7]};
+            if (F & 8) {
+                if (__builtin_expect(__any(mx > 1.0e30f), 0)) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) { Y0[i] *= 0.5f; Y1[i] *= 0.5f; }
+                }
+            }
+            if (F & 2) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
             if (!LAB_IN_CHAIN) {
                 pkA = f32x4{pk0[0], pk0[1], pk0[2], pk0[3]}; pkC = f32x4{pk1[0], pk1[1], pk1[2], pk1[3]};
                 MFMA(Y0, lab, pkA);
                 MFMA(Y1, lab, pkC);
             }
-            MFMA(Y0, lab, pkB);
-            MFMA(Y1, lab, pkD);
+            MFMA(Y0, (F & 2) ? lab2 : lab, pkB);
+            MFMA(Y1, (F & 2) ? lab2 : lab, pkD);
+            if (F & 4) {
+#pragma unroll
+                for (int i = 0; i < (INGAP ? 0 : NS); ++i) {
+                    asm volatile("s_add_i32 %0, %0, 1\n\ts_cmp_eq_u32 %0, %2\n\ts_cselect_b32 %0, 0, %0\n\ts_addc_u32 %1, %1, 0"
+                                 : "+s"(cur_a), "+s"(cur_b) : "s"(9 + i) : "scc");
+                }
+                if (F & 16) {
+                    const int rl = __builtin_amdgcn_readlane(__float_as_int(lanev), cur_a & 63);
+                    const int rl2 = __builtin_amdgcn_readlane(__float_as_int(lanev), cur_b & 63);
+                    cur_c += (rl ^ rl2) & 1;
+                }
+            }
+            if (F & 1) {
+                src_off += 16384u;
+                if (src_off + 32768u > ring_bytes) src_off = 0;
+                stg = stg == 5 * 22528 ? 0 : stg + 22528;
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     };
@@ -199,5 +238,10 @@ int main() {
     run<0, 0, 31, 5, 1>("X + all, 20 scalar instructions 4 per gap");
     run<0, 0, 11>("X + all but the cursor");
     run<0, 0, 30>("X + all but staging");
+    run<1, 0, 31>("W + all");
+    run<1, 1, 31>("W + all, two label MFMAs in the chain");
+    run<1, 0, 31, 10, 1>("W + all, the 40 scalar instructions 4 per gap");
+    run<1, 0, 1>("W + staging");
+    run<1, 0, 20>("W + cursor + readlane");
     return 0;
 }
