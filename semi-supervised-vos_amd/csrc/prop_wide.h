@@ -237,6 +237,11 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
         };
         ctl_refill(0);
         int idx = 0, ctl_base = 0;
+        // entries of the COMING step, fetched in gap 13 of the step before (the three lane reads and what hangs on them are
+        // dependent instructions: between two chains every one of them costs ~10 cycles with nothing to fill the slots)
+        unsigned flags = (unsigned)__builtin_amdgcn_readlane((int)t_flags, 0);
+        so_feat = (unsigned)__builtin_amdgcn_readlane((int)t_feat, 0);
+        so_third = (unsigned)__builtin_amdgcn_readlane((int)t_third, 0);
 
         AFrag<false> fr;
         fr.prefetch(smem, j, h);
@@ -247,12 +252,12 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
             for (int r = 0; r < 16; ++r) S1[b][r] = -__builtin_inff();   // "tile -1": every probability 0
         int s_cur = 0, s_nxt = kLdsBuf, s_prv = kRingLast, s_stg = 3 * kLdsBuf;
 
-        // the label product of tile p-1 (weights pk, labels labp); on the (rare) overflow alarm first the running maxima of BOTH
-        // blocks are raised, what was accumulated is rescaled once and the tile is redone against the new maxima
-        auto finish_prev = [&](const f32x16 (&Sp)[kBlocksW], const LabFrag<false>& labp, const float (&lt0)[kBlocksW],
-                               bf16x8 (&pk0)[kBlocksW], bf16x8 (&pk1)[kBlocksW]) __attribute__((always_inline)) {
-            const float thr = kAlarmExp / c;
-            if (VOSPROP_UNLIKELY(__any(lt0[0] > m[0] + thr || lt0[1] > m[1] + thr))) {
+        // the (rare) overflow alarm of tile p-1: the running maxima of BOTH blocks are raised, what was accumulated is rescaled once
+        // and the tile's weights are redone against the new maxima
+        auto alarm_fix = [&](const f32x16 (&Sp)[kBlocksW], const float (&lt0)[kBlocksW], bf16x8 (&pk0)[kBlocksW],
+                             bf16x8 (&pk1)[kBlocksW]) __attribute__((always_inline)) {
+            // (one compare for both blocks: `||` would make hipcc evaluate the second block's maximum lazily, under an exec mask)
+            if (VOSPROP_UNLIKELY(__any(__builtin_fmaxf(lt0[0] - m[0], lt0[1] - m[1]) > kAlarmExp / c))) {
                 asm volatile("; rescale" ::: "memory");
 #pragma unroll
                 for (int b = 0; b < kBlocksW; ++b) {
@@ -269,11 +274,30 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
                     softmax_rows<false, true>(Sp[b], Wt[b], c, mn * c, d0, d1, pk0[b], pk1[b]);
                 }
             }
-            // the four MFMAs alternate between the two accumulators: none waits for its predecessor
-            Y[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(labp.h0, pk0[0], Y[0], 0, 0, 0);
-            Y[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(labp.h0, pk0[1], Y[1], 0, 0, 0);
-            Y[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(labp.h1, pk1[0], Y[0], 0, 0, 0);
-            Y[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(labp.h1, pk1[1], Y[1], 0, 0, 0);
+        };
+        // The label product of a tile is PENDING for one step: its weights qk and labels labq wait here and its four MFMAs ride in
+        // gaps 0-3 of the next chain (one wave per SIMD hides nothing that stands between two chains; ablation: 19 of 212 us).
+        bf16x8 qk0[kBlocksW], qk1[kBlocksW];
+        LabFrag<false> labq;
+        {
+            bf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.0f;
+            labq.h0 = z;
+            labq.h1 = z;
+#pragma unroll
+            for (int b = 0; b < kBlocksW; ++b) {
+                qk0[b] = z;
+                qk1[b] = z;
+            }
+        }
+        auto pending_label_mfma = [&](int i) __attribute__((always_inline)) {
+#if !(VOSPROP_WABLATE & 1)
+            if (i == 0) Y[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(labq.h0, qk0[0], Y[0], 0, 0, 0);
+            if (i == 1) Y[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(labq.h0, qk0[1], Y[1], 0, 0, 0);
+            if (i == 2) Y[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(labq.h1, qk1[0], Y[0], 0, 0, 0);
+            if (i == 3) Y[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(labq.h1, qk1[1], Y[1], 0, 0, 0);
+#endif
         };
 
         // one step: scores of tile p into S (both blocks), softmax rows of tile p-1 (scores Sp) in the gaps of the chain
@@ -281,9 +305,9 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
             const unsigned char* lb = smem + s_cur;
             const unsigned char* lbn = smem + s_nxt;
             const unsigned b_st = smem_base + (unsigned)s_stg;
-            so_feat = (unsigned)__builtin_amdgcn_readlane((int)t_feat, idx);
-            so_third = (unsigned)__builtin_amdgcn_readlane((int)t_third, idx);
-            const unsigned flags = (unsigned)__builtin_amdgcn_readlane((int)t_flags, idx);
+            unsigned so_feat_n = 0, so_third_n = 0, flags_n = 0;
+            int s_nxt_n = 0, s_stg_n = 0;
+            const unsigned flags_now = flags;
             LabFrag<false> labp;
             float lt0[kBlocksW] = {kNegBig, kNegBig};
             float qprev[kBlocksW] = {0.0f, 0.0f};
@@ -308,6 +332,17 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
                 S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[ks & 7], Bt[0][ks], S[0], 0, 0, 0);
                 S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[ks & 7], Bt[1][ks], S[1], 0, 0, 0);
 #endif
+                if (ks < 4) pending_label_mfma(ks);      // the label product of tile p-2
+                if (ks == 5) {      // the ring one slot on (scalar; used after the barrier)
+                    s_nxt_n = s_nxt == kRingLast ? 0 : s_nxt + kLdsBuf;
+                    s_stg_n = s_stg == kRingLast ? 0 : s_stg + kLdsBuf;
+                }
+                if (ks == 13) {     // the coming step's table entries (lane idx + 1; a refill at the end of this step re-reads them)
+                    const int ix = (idx + 1) & 63;
+                    flags_n = (unsigned)__builtin_amdgcn_readlane((int)t_flags, ix);
+                    so_feat_n = (unsigned)__builtin_amdgcn_readlane((int)t_feat, ix);
+                    so_third_n = (unsigned)__builtin_amdgcn_readlane((int)t_third, ix);
+                }
                 // refill the fragment slot just consumed: second half of this tile, then the first half of the next one
 #if !(VOSPROP_WABLATE & 32)
                 if (ks < 8) fr.a[ks] = *(const bf16x8*)(arow + (ks + 8) * 32);
@@ -341,10 +376,12 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (ks & 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (ks < 4) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 if (ks & 1) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                if (ks == 5 || ks == 13) __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);      // the scalar / lane-read work placed there
 #elif VOSPROP_WIDE_SGB == 2
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
@@ -363,14 +400,20 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
             STAMP_AT(2);   // 2: gaps 8-15
 #endif
 #if !(VOSPROP_WABLATE & 1)
-            finish_prev(Sp, labp, lt0, pk0, pk1);
+            alarm_fix(Sp, lt0, pk0, pk1);
 #endif
+#pragma unroll
+            for (int b = 0; b < kBlocksW; ++b) {
+                qk0[b] = pk0[b];
+                qk1[b] = pk1[b];
+            }
+            labq = labp;
 #ifdef VOSPROP_STAMP
             STAMP_AT(3);   // 3: alarm check + label MFMAs
 #endif
             ++idx;
-            if (VOSPROP_UNLIKELY(flags & ((VOSPROP_WABLATE & 2) ? 8u : 11u))) {
-                if (flags & 1u) {      // tile p: padded rows of a frame's last tile never enter the softmax
+            if (VOSPROP_UNLIKELY(flags_now & ((VOSPROP_WABLATE & 2) ? 8u : 11u))) {
+                if (flags_now & 1u) {      // tile p: padded rows of a frame's last tile never enter the softmax
                     asm volatile("; tail tile" ::: "memory");
 #pragma unroll
                     for (int b = 0; b < kBlocksW; ++b)
@@ -378,18 +421,21 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
                         for (int r = 0; r < 16; ++r)
                             if (acc_row(r, h) >= rows_last) S[b][r] = kNegBig;
                 }
-                if (flags & 2u) {      // the prior tile of tile p (used from the next step on; tile p-1 is finished)
+                if (flags_now & 2u) {      // the prior tile of tile p (used from the next step on; tile p-1 is finished)
                     asm volatile("; prior tile" ::: "memory");
-                    const int sg_i = (flags >> 2) & 1u;
+                    const int sg_i = (flags_now >> 2) & 1u;
 #pragma unroll
                     for (int b = 0; b < kBlocksW; ++b)
                         prior_tile<true>(lb, j, h, s_bx[sg_i][b][tid], c, s_kq[sg_i][b][tid] + m[b] * c, Wt[b]);
                     w_sparse = sg_i != 0;
                 }
-                if (flags & 8u) {      // the table's last entry: the next 64 steps
+                if (flags_now & 8u) {      // the table's last entry: the next 64 steps
                     ctl_base += 64;
                     ctl_refill(ctl_base);
                     idx = 0;
+                    flags_n = (unsigned)__builtin_amdgcn_readlane((int)t_flags, 0);
+                    so_feat_n = (unsigned)__builtin_amdgcn_readlane((int)t_feat, 0);
+                    so_third_n = (unsigned)__builtin_amdgcn_readlane((int)t_third, 0);
                 }
             }
 #ifdef VOSPROP_STAMP
@@ -411,8 +457,11 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
 #endif
             s_prv = s_cur;
             s_cur = s_nxt;
-            s_nxt = s_nxt == kRingLast ? 0 : s_nxt + kLdsBuf;
-            s_stg = s_stg == kRingLast ? 0 : s_stg + kLdsBuf;
+            s_nxt = s_nxt_n;
+            s_stg = s_stg_n;
+            flags = flags_n;
+            so_feat = so_feat_n;
+            so_third = so_third_n;
         };
 
         int p = 0;
@@ -435,7 +484,17 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
                 for (int r = 0; r < 16; ++r) sv[r] = Sp[b][r];
                 lt0[b] = max16v(sv);
             }
-            finish_prev(Sp, labp, lt0, pk0, pk1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pending_label_mfma(i);      // tile n-2
+            alarm_fix(Sp, lt0, pk0, pk1);
+#pragma unroll
+            for (int b = 0; b < kBlocksW; ++b) {
+                qk0[b] = pk0[b];
+                qk1[b] = pk1[b];
+            }
+            labq = labp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pending_label_mfma(i);      // tile n-1
         };
         if (p < n_steps) {
             step(S0, S1);
