@@ -28,8 +28,8 @@
                             // the chain, 2 = no LDS fragment refills, 4 = no staging, 8 = no per-step barrier, 16 = no score MFMAs, 32 = no label MFMAs, 64 = no prior tiles
 #endif
 
-// the rare paths of the tile loop (rescale, tail tile, prior tile) are laid out OUT of the loop's straight line: a taken branch
-// costs the wave its instruction buffer
+// prop_wide.h lays the rare paths of its tile loop (rescale, tail tile, table refill) out of the loop's straight line.  (Measured on
+// this kernel too: 197-201 us with the hint on its three rare branches against 195-199 without - left as hipcc places them.)
 #ifndef VOSPROP_NO_EXPECT
 #define VOSPROP_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #else
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         // finish tile p-1: rescale check (rare), denominators, label MFMAs
         auto finish_prev = [&](const f32x16& Sp, const LabFrag<LAB_LO>& labp, float lt0, float lt1, bf16x8& pk0, bf16x8& pk1) __attribute__((always_inline)) {
             // alarm: a term of this tile above 2^8 (NEED_L: the tile's partial denominator above 2^8)
-            if (VOSPROP_UNLIKELY(__any(NEED_L ? lt0 + lt1 > kSumThrV3 : lt0 > st.m + kAlarmExp / c))) {
+            if (__any(NEED_L ? lt0 + lt1 > kSumThrV3 : lt0 > st.m + kAlarmExp / c)) {
                 // raise the running max (shared by the two half-waves of a column), rescale what was accumulated against the old
                 // one exactly once, redo this tile against the new one (cdna guide T13 hazard; Y does not hold this tile yet)
                 asm volatile("; rescale" ::: "memory");
@@ -705,14 +705,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             if (TK == 2) tkid_prev = ((unsigned)cn << 16) | (unsigned)ctile;
             ++crs;
             // tile p: padded rows of a frame's last tile never enter the softmax (wave-uniform, rare)
-            if (VOSPROP_UNLIKELY(ragged && ctile == TPF - 1)) {
+            if (ragged && ctile == TPF - 1) {
                 asm volatile("; tail tile" ::: "memory");
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (acc_row(r, h) >= rows_last) S[r] = kNegBig;
             }
             // the prior tile of tile p (used from the next step on; tile p-1 is finished)
-            if (VOSPROP_UNLIKELY(!PROB && need_w && !(VOSPROP_DABLATE & 64))) {
+            if (!PROB && need_w && !(VOSPROP_DABLATE & 64)) {
                 asm volatile("; prior tile" ::: "memory");
                 prior_tile<FUSED>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c,
                                   s_kq[sparse ? 1 : 0][tid] + (FUSED && TK == 0 ? st.m * c : 0.0f), Wt);      // (top-k: log2 w itself)

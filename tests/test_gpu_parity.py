@@ -462,3 +462,17 @@ def test_mask_only_step_at_full_480p_vs_oracle(vos, dev, peaky):
         checked += int(clear.sum())
     assert checked > 4000
     assert len(np.unique(cls_hist[20])) >= 3        # the objects survive 20 propagations
+
+
+def test_wide_shape_of_the_mask_only_kernel_vs_oracle():
+    """prop_wide.h - the mask-only dense kernel as four waves x 64 columns (experimental, selected by VOSPROP_WIDE=1, which the
+    library reads once per process): the same oracle check as above and the small mask-only cases, in a child process with the
+    switch set.  Keeps the second shape honest while it is not the shipped one."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VOSPROP_WIDE='1')
+    r = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        '-k', 'mask_only_step_at_full_480p_vs_oracle or rescale or edge'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
