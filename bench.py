@@ -317,7 +317,7 @@ def main():
     ap.add_argument('--no-miopen-find', action='store_true',
                     help='take MIOpen\'s immediate-mode convolution algorithms instead of letting it time its solvers in the warm-up')
     ap.add_argument('--prime', type=int, default=20, help='untimed frames that fill the reference history')
-    ap.add_argument('--encoder-batch', type=int, default=64,
+    ap.add_argument('--encoder-batch', type=int, default=96,
                     help='frames encoded per encoder call (features do not depend on the propagated labels)')
     args = ap.parse_args()
 
