@@ -131,6 +131,24 @@ def test_edge_shapes(vos, dev, Hd, Wd, T, d, fi):
     eng.close()
 
 
+def test_sixty_four_reference_frames(vos, dev):
+    """VOSPROP_MAX_REF = 64 sampled frames - every lane of the kernels' per-frame offset table in use (lane n holds frame n's ring
+    offsets), frame_idx > 15 so that both sigma classes are live; the reference's sample_frames with ref_num = 64 picks 4 continuous
+    + 60 interval frames (src/model/predict.py:13-37)."""
+    Hd, Wd, T, d, fi = 6, 5, 101, 4, 100
+    feats, oh = _random_case(99, Hd, Wd, T, d)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=64, frame_range=100)
+    wd, ws = vo.get_spatial_weight((Hd, Wd), 8.0), vo.get_spatial_weight((Hd, Wd), 21.0)
+    fd, ld = torch.from_numpy(feats).to(dev), torch.from_numpy(oh).to(dev)
+    for prob in (False, True):
+        got = eng.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 100, 64, 1.0, 8.0, 21.0, prob).cpu().numpy()
+        want = vo.predict(feats[:fi], feats[fi], oh[:, :fi], None if prob else wd, None if prob else ws, fi, 100, 64,
+                          1.0, prob).numpy()
+        check_close(got, want, rel=4e-3)
+    assert eng.last_stats()['n_ref'] == 64
+    eng.close()
+
+
 def test_peaky_logits_force_rescale(vos, dev):
     """Online-softmax rescale path: logits with sigma ~ 16 and a spike that raises one column's running max
     late in the stream (cdna guide rule 26: force the rare branch)."""
