@@ -23,6 +23,7 @@ constexpr float kTkDummy = -3.0e38f;   // "no group": below every real weighted 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // Row of a 32x32 MFMA accumulator held in register `reg` by a lane of half `h` (= lane >> 5):

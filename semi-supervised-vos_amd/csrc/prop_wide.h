@@ -20,6 +20,9 @@ namespace vosprop {
 #ifndef VOSPROP_WABLATE
 #define VOSPROP_WABLATE 0   // timing experiments only (results wrong): 1 no alarm / label MFMAs, 2 no rare block, 4 no staging, 8 no barrier, 16 no softmax rows, 32 no fragment refills, 64 no score MFMAs
 #endif
+#ifndef VOSPROP_WIDE_ASM
+#define VOSPROP_WIDE_ASM 1     // the chain's gaps as hand-ordered asm statements (0: the form hipcc schedules)
+#endif
 #ifndef VOSPROP_WIDE_SGB
 #define VOSPROP_WIDE_SGB 1
 #endif
@@ -245,6 +248,14 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
 
         AFrag<false> fr;
         fr.prefetch(smem, j, h);
+#if VOSPROP_WIDE_ASM
+        // the loop refills these registers from asm statements hipcc's wait-count pass cannot see: make the values asm-defined here
+        // too, or the pass keeps the prologue's eight reads "pending" around the back edge and drains the queue (lgkmcnt(0)) in
+        // gap 7 of every step
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(fr.a[k]));
+#endif
         f32x16 S0[kBlocksW], S1[kBlocksW];
 #pragma unroll
         for (int b = 0; b < kBlocksW; ++b)
@@ -314,10 +325,17 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
             bf16x8 pk0[kBlocksW], pk1[kBlocksW];
             const unsigned char* arow = lb + j * kRowB + h * 16;
             const unsigned char* nrow = lbn + j * kRowB + h * 16;
+#if VOSPROP_WIDE_ASM
+            const unsigned a_addr = smem_base + (unsigned)s_cur + (unsigned)(j * kRowB + h * 16);      // LDS byte addresses
+            const unsigned n_addr = smem_base + (unsigned)s_nxt + (unsigned)(j * kRowB + h * 16);
+            const unsigned lab_addr = smem_base + (unsigned)s_prv + (unsigned)(kOffLabHi + lane * 16);
+            unsigned pkw[kBlocksW][8];
+#else
 #pragma unroll
             for (int b = 0; b < kBlocksW; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[b][r] = 0.0f;
+#endif
 #ifdef VOSPROP_STAMP
             STAMP_AT(0);   // 0: step head
 #endif
@@ -325,6 +343,94 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
             for (int ks = 0; ks < 16; ++ks) {
 #ifdef VOSPROP_STAMP
                 if (ks == 8) STAMP_AT(1);   // 1: gaps 0-7
+#endif
+#if VOSPROP_WIDE_ASM
+                {
+                    // ---- one gap, hand-ordered: MFMA (block 0) ; the two rows' fma ; first exponential ; MFMA (block 1) ; the
+                    // fragment refill ; second exponential ; (odd gaps) the alarm's running maxima and the two packs.  Every
+                    // instruction of the chain sits in a volatile asm statement: the ORDER is the one written here.  The LDS reads of
+                    // these statements are invisible to hipcc's wait-count pass and are waited for HERE: a fragment was read eight
+                    // gaps ago, seven refills (and at most the two label reads) are younger -> lgkmcnt(7) (LDS returns in order).
+                    bf16x8& fa = fr.a[ks & 7];
+                    const unsigned rd_addr = ks < 8 ? a_addr : n_addr;
+                    float q0, q1;
+                    if (ks == 0) {      // (the accumulators start from the inline constant 0: no zeroing)
+                        asm volatile("s_waitcnt lgkmcnt(7)\n\t"
+                                     "v_mfma_f32_32x32x16_bf16 %[s0], %[fa], %[b0], 0\n\t"
+                                     "v_fma_f32 %[q0], %[sp0], %[c], %[w0]\n\t"
+                                     "v_fma_f32 %[q1], %[sp1], %[c], %[w1]\n\t"
+                                     "v_exp_f32 %[q0], %[q0]\n\t"
+                                     "v_mfma_f32_32x32x16_bf16 %[s1], %[fa], %[b1], 0\n\t"
+                                     "ds_read_b128 %[fa], %[ad] offset:%[off]\n\t"
+                                     "v_exp_f32 %[q1], %[q1]"
+                                     : [s0] "=&v"(S[0]), [s1] "=&v"(S[1]), [q0] "=&v"(q0), [q1] "=&v"(q1), [fa] "+v"(fa)
+                                     : [b0] "a"(Bt[0][ks]), [b1] "a"(Bt[1][ks]), [sp0] "v"(Sp[0][ks]), [sp1] "v"(Sp[1][ks]),
+                                   [w0] "v"(Wt[0][ks]), [w1] "v"(Wt[1][ks]), [c] "s"(c), [ad] "v"(rd_addr), [off] "n"(((ks & 7) + (ks < 8 ? 8 : 0)) * 32)
+                                     : "memory");
+                        qprev[0] = q0;
+                        qprev[1] = q1;
+                    } else if (!(ks & 1)) {
+                        asm volatile("s_waitcnt lgkmcnt(7)\n\t"
+                                     "v_mfma_f32_32x32x16_bf16 %[s0], %[fa], %[b0], %[s0]\n\t"
+                                     "v_fma_f32 %[q0], %[sp0], %[c], %[w0]\n\t"
+                                     "v_fma_f32 %[q1], %[sp1], %[c], %[w1]\n\t"
+                                     "v_exp_f32 %[q0], %[q0]\n\t"
+                                     "v_mfma_f32_32x32x16_bf16 %[s1], %[fa], %[b1], %[s1]\n\t"
+                                     "ds_read_b128 %[fa], %[ad] offset:%[off]\n\t"
+                                     "v_exp_f32 %[q1], %[q1]"
+                                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [q0] "=&v"(q0), [q1] "=&v"(q1), [fa] "+v"(fa)
+                                     : [b0] "a"(Bt[0][ks]), [b1] "a"(Bt[1][ks]), [sp0] "v"(Sp[0][ks]), [sp1] "v"(Sp[1][ks]),
+                                   [w0] "v"(Wt[0][ks]), [w1] "v"(Wt[1][ks]), [c] "s"(c), [ad] "v"(rd_addr), [off] "n"(((ks & 7) + (ks < 8 ? 8 : 0)) * 32)
+                                     : "memory");
+                        qprev[0] = q0;
+                        qprev[1] = q1;
+                    } else {
+                        unsigned w0, w1;
+                        asm volatile("s_waitcnt lgkmcnt(7)\n\t"
+                                     "v_mfma_f32_32x32x16_bf16 %[s0], %[fa], %[b0], %[s0]\n\t"
+                                     "v_fma_f32 %[q0], %[sp0], %[c], %[w0]\n\t"
+                                     "v_fma_f32 %[q1], %[sp1], %[c], %[w1]\n\t"
+                                     "v_exp_f32 %[q0], %[q0]\n\t"
+                                     "v_max3_f32 %[l0], %[l0], %[pp0], %[sp0]\n\t"
+                                     "v_mfma_f32_32x32x16_bf16 %[s1], %[fa], %[b1], %[s1]\n\t"
+                                     "ds_read_b128 %[fa], %[ad] offset:%[off]\n\t"
+                                     "v_exp_f32 %[q1], %[q1]\n\t"
+                                     "v_max3_f32 %[l1], %[l1], %[pp1], %[sp1]\n\t"
+                                     "v_cvt_pk_bf16_f32 %[k0], %[qp0], %[q0]\n\t"
+                                     "v_cvt_pk_bf16_f32 %[k1], %[qp1], %[q1]"
+                                     : [s0] "+v"(S[0]), [s1] "+v"(S[1]), [q0] "=&v"(q0), [q1] "=&v"(q1), [fa] "+v"(fa),
+                                       [l0] "+v"(lt0[0]), [l1] "+v"(lt0[1]), [k0] "=&v"(w0), [k1] "=&v"(w1)
+                                     : [b0] "a"(Bt[0][ks]), [b1] "a"(Bt[1][ks]), [sp0] "v"(Sp[0][ks]), [sp1] "v"(Sp[1][ks]),
+                                   [w0] "v"(Wt[0][ks]), [w1] "v"(Wt[1][ks]), [c] "s"(c), [ad] "v"(rd_addr), [off] "n"(((ks & 7) + (ks < 8 ? 8 : 0)) * 32),
+                                       [pp0] "v"(Sp[0][ks - 1]), [pp1] "v"(Sp[1][ks - 1]), [qp0] "v"(qprev[0]), [qp1] "v"(qprev[1])
+                                     : "memory");
+                        pkw[0][ks >> 1] = w0;
+                        pkw[1][ks >> 1] = w1;
+                    }
+                    if (ks < 4) {      // the label product of tile p-2 (same statement kind: its place in the chain is fixed too)
+                        f32x16& Yb = Y[ks & 1];
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %[y], %[l], %[k], %[y]"
+                                     : [y] "+v"(Yb)
+                                     : [l] "v"(ks < 2 ? labq.h0 : labq.h1), [k] "v"(ks < 2 ? qk0[ks & 1] : qk1[ks & 1]));
+                    }
+                    if (ks % 3 == 1) stage_piece(b_st, ks / 3);      // gaps 1, 4, 7, 10, 13: pieces 0..4 of tile p+3
+                    if (ks == 10)      // labels of tile p-1 (waited for by the lgkmcnt(7) of the next chain's first gaps)
+                        asm volatile("ds_read_b128 %[h0], %[ad]\n\tds_read_b128 %[h1], %[ad] offset:1024"
+                                     : [h0] "=&v"(labp.h0), [h1] "=&v"(labp.h1)
+                                     : [ad] "v"(lab_addr)
+                                     : "memory");
+                    if (ks == 5) {
+                        s_nxt_n = s_nxt == kRingLast ? 0 : s_nxt + kLdsBuf;
+                        s_stg_n = s_stg == kRingLast ? 0 : s_stg + kLdsBuf;
+                    }
+                    if (ks == 13) {
+                        const int ix = (idx + 1) & 63;
+                        flags_n = (unsigned)__builtin_amdgcn_readlane((int)t_flags, ix);
+                        so_feat_n = (unsigned)__builtin_amdgcn_readlane((int)t_feat, ix);
+                        so_third_n = (unsigned)__builtin_amdgcn_readlane((int)t_third, ix);
+                    }
+                    continue;
+                }
 #endif
 #if VOSPROP_WABLATE & 64
                 asm volatile("" : "+v"(fr.a[ks & 7]));
@@ -394,8 +500,16 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
 #endif
 #endif
             }
+#if VOSPROP_WIDE_ASM
+#pragma unroll
+            for (int b = 0; b < kBlocksW; ++b) {
+                pk0[b] = __builtin_bit_cast(bf16x8, u32x4{pkw[b][0], pkw[b][1], pkw[b][2], pkw[b][3]});
+                pk1[b] = __builtin_bit_cast(bf16x8, u32x4{pkw[b][4], pkw[b][5], pkw[b][6], pkw[b][7]});
+            }
+#else
 #pragma unroll
             for (int b = 0; b < kBlocksW; ++b) asm volatile("" : "+v"(pk0[b]), "+v"(pk1[b]));
+#endif
 #ifdef VOSPROP_STAMP
             STAMP_AT(2);   // 2: gaps 8-15
 #endif
@@ -450,7 +564,11 @@ __global__ __launch_bounds__(kWavesW * 64, 1) void prop_wide_kernel(const PropAr
             STAMP_AT(5);   // 5: wait for the own pieces of tile p+2
 #endif
 #if !(VOSPROP_WABLATE & 8)
+#if VOSPROP_WIDE_ASM
+            asm volatile("s_barrier" ::: "memory");      // (the fragment reads of tile p+1 may stay in flight across it: nobody writes that slot)
+#else
             __syncthreads();
+#endif
 #endif
 #ifdef VOSPROP_STAMP
             STAMP_AT(6);   // 6: barrier
