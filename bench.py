@@ -204,31 +204,43 @@ def end_to_end_leg(args, wl, dev, clip, pool, net, eng, enc_dtype, fence, world,
             masks_home[k % 2].record(copy_stream)
 
     n_batches = (K + B - 1) // B
-    # a fresh video, primed (untimed) on the clip's first n_prime frames to frame_idx >= 17: the leg then continues the clip, its
-    # masks hold the three objects of the annotation instead of whatever hundreds of timed steps on a noise clip left of them
-    eng.begin_video(ann)
-    with torch.no_grad():
-        pf = net(clip[:n_prime].contiguous(memory_format=torch.channels_last))
-    for i in range(n_prime):
-        eng.step(pf[i][None], want_pred=False, want_mask=False)
-    del pf
+
+    def fresh_video():
+        # a fresh video, primed (untimed) on the clip's first n_prime frames to frame_idx >= 17: the leg then continues the clip,
+        # its masks hold the three objects of the annotation instead of whatever hundreds of timed steps left of them
+        eng.begin_video(ann)
+        with torch.no_grad():
+            pf = net(clip[:n_prime].contiguous(memory_format=torch.channels_last))
+        for i in range(n_prime):
+            eng.step(pf[i][None], want_pred=False, want_mask=False)
+
+    def run(nb):
+        upload(0)
+        for k in range(nb):
+            n = min(B, K - k * B)
+            if k + 1 < nb:
+                upload(k + 1)
+            main.wait_event(copied[k % 2])
+            with torch.no_grad():
+                x = ds.normalize_on_device(bufs[k % 2][:n]).to(enc_dtype).contiguous(memory_format=torch.channels_last)
+                consumed[k % 2].record(main)
+                feats = net(x)
+            if k >= 2:
+                main.wait_event(masks_home[k % 2])
+            for i in range(n):
+                eng.step(feats[i][None], want_pred=False, mask_out=mask_dev[k % 2][i])
+            download(k, n)
+
+    # one untimed batch through the whole pipeline first (the copy stream, the pinned buffers' first DMA, the normalisation's
+    # kernels and look-up table: first-use costs of ~10 ms that a 20-step run would otherwise report as throughput)
+    fresh_video()
+    run(1)
+    fence()
+    masks_host.fill_(255)
+    fresh_video()
     fence()
     t0 = time.perf_counter()
-    upload(0)
-    for k in range(n_batches):
-        n = min(B, K - k * B)
-        if k + 1 < n_batches:
-            upload(k + 1)
-        main.wait_event(copied[k % 2])
-        with torch.no_grad():
-            x = ds.normalize_on_device(bufs[k % 2][:n]).to(enc_dtype).contiguous(memory_format=torch.channels_last)
-            consumed[k % 2].record(main)
-            feats = net(x)
-        if k >= 2:
-            main.wait_event(masks_home[k % 2])
-        for i in range(n):
-            eng.step(feats[i][None], want_pred=False, mask_out=mask_dev[k % 2][i])
-        download(k, n)
+    run(n_batches)
     fence()
     dt = time.perf_counter() - t0
     # every mask is on the host (no 255 left), the last batch equals what the device holds, and the labels did not collapse
@@ -388,7 +400,11 @@ def main():
     if not args.no_encoder_graph:
         net = vos_net.GraphedEncoder(net, max_graphs=8)     # the look-ahead batch forward as one HIP graph launch per shape
 
-    pool = 32                                    # distinct frames, cycled
+    # one distinct frame per step of the whole run (primed + warm-up + timed), resident in HBM, capped at 1 024 frames (cycled beyond
+    # that): a look-ahead batch is then a VIEW of consecutive frames - round 2 / early round 3 cycled 32 frames and GATHERED every
+    # batch (index_select + a channels-last copy, 3.8 us per frame of the timed region that no real pipeline has: there the batch
+    # arrives in its buffer by DMA)
+    pool = min(1024, max(args.prime, 17) + args.warmup + args.steps + 1)
     clip, ann = synthetic_clip(H, W, pool, seed=rank, device=dev)
     clip = clip.to(enc_dtype).contiguous(memory_format=torch.channels_last)
     eng = vos.PropagationEngine(Hd, Wd, device=local, ref_num=wl['ref_num'], frame_range=cfg['frame_range'],
@@ -401,13 +417,20 @@ def main():
     B = max(1, args.encoder_batch)
     feat_buf = {'f': None, 'pos': 0}
 
+    def frames_of(i, n):
+        """frames i .. i+n-1 of the clip (a ring of `pool` frames): a view when they are consecutive in memory, a gather at the wrap"""
+        a = i % pool
+        if a + n <= pool:
+            return clip[a:a + n]
+        idx = torch.arange(i, i + n, device=dev) % pool
+        return clip.index_select(0, idx).contiguous(memory_format=torch.channels_last)
+
     def encode_next(i, end):
         """Encoder look-ahead: the features of frames i .. min(i+B, end)-1 in one call (never a frame past `end`: a phase only
         encodes what it uses); the propagation stays strictly sequential."""
         if feat_buf['f'] is None or feat_buf['pos'] == feat_buf['f'].shape[0]:
-            idx = torch.arange(i, min(i + B, end), device=dev) % pool
             with torch.no_grad():
-                feat_buf['f'] = net(clip.index_select(0, idx).contiguous(memory_format=torch.channels_last))
+                feat_buf['f'] = net(frames_of(i, min(i + B, end) - i))
             feat_buf['pos'] = 0
         f = feat_buf['f'][feat_buf['pos']]
         feat_buf['pos'] += 1
@@ -442,9 +465,8 @@ def main():
     # batch shapes are run once here, untimed, so that MIOpen's one-off algorithm search (and the HIP-graph capture) for a
     # new batch size is not inside the timing
     for n_warm in sorted({min(B, args.steps), args.steps % B} - {0}, reverse=True):
-        idx = torch.arange(n_warm, device=dev) % pool
         with torch.no_grad():
-            net(clip.index_select(0, idx).contiguous(memory_format=torch.channels_last))
+            net(frames_of(0, n_warm))
     feat_buf['f'] = None   # the timed region starts with an empty look-ahead buffer: it pays for every frame it uses
     t_end = fi + args.steps
 
@@ -487,8 +509,7 @@ def main():
     prop_fps = 50 / (time.perf_counter() - t1)
 
     # the encoder alone: the look-ahead batch replayed 5 times back to back (same graph, same input shape as the timed region)
-    idx = torch.arange(min(B, args.steps), device=dev) % pool
-    xb = clip.index_select(0, idx).contiguous(memory_format=torch.channels_last)
+    xb = frames_of(0, min(B, args.steps))
     with torch.no_grad():
         net(xb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
