@@ -402,7 +402,13 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
     // dense path: the in-wave pipelined kernel (prop_dense.h).  VOSPROP_DENSE_TWO_BURST=1 selects the round-1 two-burst schedule of
     // prop_bf16.h (same results; A/B timing only)
     static const bool two_burst = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
-    static const bool wide = getenv("VOSPROP_WIDE") ? atoi(getenv("VOSPROP_WIDE")) != 0 : false;
+    // the four-wave shape of the mask-only kernel (prop_wide.h) has the faster tile loop and the dearer segment start: measured in
+    // bench.py's loop it wins where a workgroup walks many tiles (720p, ~900 tile steps per workgroup: 814 against 826 us) and loses
+    // where it walks few (480p, 184 steps: 189 against 182 us; 240p: 30 against 26) - taken from 512 steps per workgroup up.
+    // VOSPROP_WIDE=0 / 1 forces either shape (A/B, tests).
+    static const int wide_env = getenv("VOSPROP_WIDE") ? atoi(getenv("VOSPROP_WIDE")) : -1;
+    const long long steps_per_wg = (long long)a.n_ref * a.tiles_per_frame * ((a.HWp + kBT - 1) / kBT) / (lp.grid > 0 ? lp.grid : 1);
+    const bool wide = wide_env >= 0 ? wide_env != 0 : steps_per_wg >= 512;
     if (lp.materialise) {   // the materialised-affinity variant: score tiles out to HBM, then back in (prop_dense.h MAT 1 / 2)
         if (lp.prob) {
             hipLaunchKernelGGL((prop_dense_kernel<true, true, 1>), grid, block, 0, s, a);

@@ -482,10 +482,58 @@ def test_mask_only_step_at_full_480p_vs_oracle(vos, dev, peaky):
     assert len(np.unique(cls_hist[20])) >= 3        # the objects survive 20 propagations
 
 
+def test_mask_only_step_at_720p_takes_the_wide_kernel_and_matches_the_oracle(vos, dev):
+    """At 720p (90x160 map, N = 9: ~900 tile steps per workgroup) the engine launches the four-wave shape of the mask-only kernel by
+    itself (engine.hip launch_prop_mode: from 512 steps per workgroup up).  A 19-frame roll-out of mask-only steps; at frames 17
+    and 18 (frame_idx > 15: both sigma classes) the class map must be the arg-max of the oracle's predict_columns, fed with the
+    engine's own label history, on every sampled column with a clear top-2 margin."""
+    H, W = 720, 1280
+    Hd, Wd = vos.feature_map_size(H, W)
+    HW = Hd * Wd
+    rs = np.random.RandomState(720)
+    ann = np.zeros((H, W), np.uint8)
+    ann[100:400, 150:600] = 1
+    ann[300:650, 500:1100] = 2
+    ann[50:200, 900:1200] = 3
+    d, T = 4, 19
+    base = rs.randn(256, Hd, Wd).astype(np.float32)
+    feats = []
+    for t in range(T):
+        base = 0.9 * base + 0.45 * rs.randn(256, Hd, Wd).astype(np.float32)
+        feats.append(bf16_round(base * 0.25))
+    feats = np.stack(feats)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=9, frame_range=40)
+    eng.begin_video(ann)
+    cls_hist = [np.asarray(vo.get_labels(ann.astype(np.int64), d, H, W, Hd, Wd)).reshape(d, HW).argmax(0).astype(np.uint8)]
+    for t in range(T):
+        f = torch.from_numpy(feats[t]).to(dev).to(torch.bfloat16)[None].contiguous(memory_format=torch.channels_last)[0]
+        pred, mask = eng.step(f, want_pred=False, want_mask=True)
+        assert pred is None
+        if t:
+            cls_hist.append(_lowres_from_mask(mask.cpu().numpy(), Hd, Wd).reshape(-1))
+    st = eng.last_stats()
+    eng.close()
+    assert st['n_ref'] == 9 and st['hw'] == HW
+    onehot = np.zeros((d, T, HW), np.float32)
+    for t in range(T):
+        onehot[cls_hist[t], t, np.arange(HW)] = 1.0
+    checked = 0
+    for fi in (17, 18):
+        cols = np.sort(rs.choice(HW, 1200, replace=False))
+        want = vo.predict_columns(feats[:fi], feats[fi], onehot[:, :fi], 8.0, 21.0, fi, 40, 9, 1.0, False, cols).numpy()
+        srt = np.sort(want, axis=0)
+        clear = (srt[-1] - srt[-2]) > 1e-2 * srt[-1]
+        bad = cls_hist[fi][cols][clear] != want.argmax(0)[clear]
+        assert not bad.any(), f'frame {fi}: {int(bad.sum())} of {int(clear.sum())} clear-margin columns differ'
+        checked += int(clear.sum())
+    assert checked > 1000
+    assert len(np.unique(cls_hist[18])) >= 3
+
+
 def test_wide_shape_of_the_mask_only_kernel_vs_oracle():
-    """prop_wide.h - the mask-only dense kernel as four waves x 64 columns (experimental, selected by VOSPROP_WIDE=1, which the
-    library reads once per process): the same oracle check as above and the small mask-only cases, in a child process with the
-    switch set.  Keeps the second shape honest while it is not the shipped one."""
+    """prop_wide.h - the mask-only dense kernel as four waves x 64 columns, which the engine takes by itself only for large maps
+    (previous test): here forced with VOSPROP_WIDE=1 (read once per process, hence a child process) through the 480p oracle check
+    and the small mask-only cases."""
     import os
     import subprocess
     import sys
