@@ -565,7 +565,8 @@ def main():
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
             'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us, 'end_to_end': end_to_end,
             'roofline': {'kernel': ('prop_dense_kernel<.,.,1> + <.,.,2> (affinity out to HBM, then back)' if hbm_bound else
-                                    'prop_dense_kernel<TK=1> + topk_select2_kernel + prop_dense_kernel<TK=2> (one scoring pass, select, re-score of the marked tiles)' if wl['topk'] else 'prop_dense_kernel<mask-only form>'),
+                                    'prop_dense_kernel<TK=1> + topk_select2_kernel + prop_dense_kernel<TK=2> (one scoring pass, select, re-score of the marked tiles)' if wl['topk'] else ('prop_wide_kernel (mask-only form, four waves x 64 columns)' if st['tiles_per_wg'] >= 512 and os.environ.get('VOSPROP_WIDE', '') != '0'
+                                     or os.environ.get('VOSPROP_WIDE', '') == '1' else 'prop_dense_kernel<mask-only form>')),
                          'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': achieved_gbs if hbm_bound else achieved,
                          'peak': HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TFLOPS, 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                          'frac': achieved_gbs / HBM_PEAK_GBS if hbm_bound else achieved / MFMA_BF16_PEAK_TFLOPS,
