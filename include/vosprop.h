@@ -203,7 +203,18 @@ typedef struct vosprop_stats {
     int tiles_per_wg;       /* reference tiles (32 rows) each workgroup walks      */
     double flops;           /* algorithmic FLOP of the step, counted once: 2*N*HW^2*C + 2*d*N*HW^2 (top-k: + 2*d*k*HW) */
     double bytes;           /* algorithmic bytes: N*HW*C*2 + HW*C*2 + N*HW + d*HW*4   */
+    int kernel_id;          /* which propagation kernel the engine LAUNCHED for the step: VOSPROP_KERNEL_* (set where the launch is
+                               decided, so a bench line or a test never re-derives the dispatch rule) */
+    int reserved_;
 } vosprop_stats;
+/* vosprop_stats.kernel_id */
+#define VOSPROP_KERNEL_DENSE        1   /* prop_dense_kernel: dense, softmax denominators kept (a prediction was requested, or probability mode) */
+#define VOSPROP_KERNEL_MASK         2   /* prop_mask_kernel: the hand-ordered mask-only label-mode step (frame loop, bench.py) */
+#define VOSPROP_KERNEL_TOPK         3   /* prop_dense_kernel<TK 1> + topk_select2 + prop_dense_kernel<TK 2> */
+#define VOSPROP_KERNEL_F32          4   /* prop_f32_kernel (VOSPROP_PREC_F32) */
+#define VOSPROP_KERNEL_MATERIALISED 5   /* prop_dense_kernel<MAT 1> + <MAT 2> (affinity through HBM) */
+/* name of a VOSPROP_KERNEL_* value ("prop_mask_kernel" ...), or "?" */
+const char* vosprop_kernel_name(int kernel_id);
 int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out);
 
 /* Measure the propagation kernel alone: re-runs the last step's propagation `iters` times on

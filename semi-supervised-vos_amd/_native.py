@@ -32,7 +32,12 @@ class Config(ctypes.Structure):
 class Stats(ctypes.Structure):
     """Mirror of `vosprop_stats`."""
     _fields_ = [('n_ref', ctypes.c_int), ('hw', ctypes.c_int), ('workgroups', ctypes.c_int),
-                ('tiles_per_wg', ctypes.c_int), ('flops', ctypes.c_double), ('bytes', ctypes.c_double)]
+                ('tiles_per_wg', ctypes.c_int), ('flops', ctypes.c_double), ('bytes', ctypes.c_double),
+                ('kernel_id', ctypes.c_int), ('reserved_', ctypes.c_int)]
+
+
+# vosprop_stats.kernel_id (include/vosprop.h VOSPROP_KERNEL_*)
+KERNEL_DENSE, KERNEL_MASK, KERNEL_TOPK, KERNEL_F32, KERNEL_MATERIALISED = 1, 2, 3, 4, 5
 
 
 # every symbol include/vosprop.h declares: name -> (restype, argtypes)
@@ -62,6 +67,7 @@ SYMBOLS = {
                                        ctypes.c_int, _vp, _vp]),
     'vosprop_sample_frames': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     'vosprop_last_stats': (ctypes.c_int, [_vp, ctypes.POINTER(Stats)]),
+    'vosprop_kernel_name': (ctypes.c_char_p, [ctypes.c_int]),
     'vosprop_time_last_propagation': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_double)]),
 }
 

@@ -18,7 +18,7 @@
 #include "common.h"
 #include "prop_bf16.h"
 #include "prop_dense.h"
-#include "prop_wide.h"
+#include "prop_mask.h"
 #include "prop_f32.h"
 #include "pointwise.h"
 #include "encoder_ops.h"
@@ -77,6 +77,9 @@ struct vosprop_ctx {
     Ring scratch;         // stateless vosprop_predict
     bf16_t* coord_tab = nullptr;
     float2* coord_f32 = nullptr;   // [HWp] the reference's f32 pixel coordinates (f32 path)
+    uint16_t* tc_b = nullptr;      // prop_mask_kernel: target-side prior constants (build_target_consts) ...
+    float* tc_kq = nullptr;
+    float tc_sig1 = 0.f, tc_sig2 = 0.f, tc_temp = 0.f;   // ... and what they were built for
     float* part = nullptr;
     size_t part_bytes = 0;
     bf16_t* smat = nullptr;        // materialised-affinity variant: score tiles in HBM (grown on demand)
@@ -167,7 +170,10 @@ void ring_free(Ring& r) {
 }
 
 // Reference-side spatial channels, [tile][half][row][8]: per pixel p=(a,b):
-//   ch0-2: a   ch3-5: b   ch6-8: Qh   ch9-10: Qm   ch11: Ql   ch12-15: 0,   Q = a^2 + (2/W) a b + (1 + 1/W^2) b^2.
+//   ch0-2: a   ch3-5: b   ch6-8: Qh   ch9-10: Qm   ch11: Ql,   Q = a^2 + (2/W) a b + (1 + 1/W^2) b^2;
+//   ch12-14: 1 (prop_mask.h: they carry the 3-way split of the column constant -(g Q_t c + M) on the target side; the other kernels
+//   put 0 there);  ch15: 1 for the PADDED rows of the last tile (all their other channels are 0) - against a target-side -1e30 it
+//   takes them out of the softmax.
 int build_coord_table(vosprop_ctx* ctx) {
     const int W = ctx->cfg.feat_w;
     std::vector<uint16_t> tab((size_t)ctx->HWp * kCoordCh, 0);
@@ -178,10 +184,14 @@ int build_coord_table(vosprop_ctx* ctx) {
         const float qh = bf16_round((float)Q);
         const float qm = bf16_round((float)(Q - qh));
         const float ql = bf16_round((float)(Q - qh - qm));
-        float ch[kCoordCh] = {(float)a, (float)a, (float)a, (float)b, (float)b, (float)b, qh, qh, qh, qm, qm, ql, 0, 0, 0, 0};
+        float ch[kCoordCh] = {(float)a, (float)a, (float)a, (float)b, (float)b, (float)b, qh, qh, qh, qm, qm, ql, 1, 1, 1, 0};
         const int tile = p / kTileR, row = p % kTileR;
         for (int c = 0; c < kCoordCh; ++c)
             tab[(((size_t)tile * 2 + c / 8) * 32 + row) * 8 + (c % 8)] = bf16_bits(ch[c]);
+    }
+    for (int p = ctx->HW; p < ctx->HWp; ++p) {
+        const int tile = p / kTileR, row = p % kTileR;
+        tab[(((size_t)tile * 2 + 1) * 32 + row) * 8 + 7] = bf16_bits(1.0f);
     }
     HIP_TRY(ctx, hipMalloc((void**)&ctx->coord_tab, tab.size() * 2));
     HIP_TRY(ctx, hipMemcpy(ctx->coord_tab, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
@@ -196,6 +206,56 @@ int build_coord_f32(vosprop_ctx* ctx) {
     for (int p = 0; p < ctx->HW; ++p) tab[(size_t)p] = make_float2((float)p / (float)W, (float)(p % W));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->coord_f32, tab.size() * sizeof(float2)));
     HIP_TRY(ctx, hipMemcpy(ctx->coord_f32, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    return VOSPROP_OK;
+}
+
+// Target-side constants of prop_mask_kernel's prior MFMA for one (sigma1, sigma2, temperature): per target pixel t = (a_t, b_t)
+// and sigma class, the B fragment that pairs with build_coord_table's channels - with c = temperature log2(e) folded in, so the MFMA
+// yields log2 w + (the column constant) directly:
+//   k half 0: split3(c g (2 a_t + (2/W) b_t)), split3(c g (2 gamma b_t + (2/W) a_t)), the first two parts of split3(-c g)
+//   k half 1: the third part and again the first two of split3(-c g) (against Qh, Qm, Qm, Ql), split3(-c g Q_t), -1e30
+// and kq = c g Q_t as f32 (the kernel re-splits -(kq + M) when a column's reference level M moves).  g = 1 / (sigma^2 temperature).
+int build_target_consts(vosprop_ctx* ctx, float sigma1, float sigma2, float temperature) {
+    if (ctx->tc_b && ctx->tc_sig1 == sigma1 && ctx->tc_sig2 == sigma2 && ctx->tc_temp == temperature) return VOSPROP_OK;
+    const int W = ctx->cfg.feat_w, HWp = ctx->HWp;
+    std::vector<uint16_t> tb((size_t)2 * HWp * 16, 0);
+    std::vector<float> kq((size_t)2 * HWp, 0.f);
+    const double tw = 2.0 / W, gm = 1.0 + 1.0 / ((double)W * W);
+    const double c = (double)temperature * 1.4426950408889634;
+    for (int sg = 0; sg < 2; ++sg) {
+        const double sigma = sg ? sigma2 : sigma1;
+        const double g = 1.0 / (sigma * sigma * (double)temperature);
+        for (int t = 0; t < HWp; ++t) {
+            const int tq = t < ctx->HW ? t : ctx->HW - 1;
+            const double at = tq / W, bt = tq % W;
+            const double qt = at * at + tw * at * bt + gm * bt * bt;
+            float ah, am, al, bh, bm, bl, kh, km, kl, sh, sm, sl;
+            split3((float)(c * g * (2.0 * at + tw * bt)), ah, am, al);
+            split3((float)(c * g * (2.0 * gm * bt + tw * at)), bh, bm, bl);
+            split3((float)(-c * g), kh, km, kl);
+            const float kqf = (float)(c * g * qt);
+            split3(-kqf, sh, sm, sl);
+            const float lo[8] = {ah, am, al, bh, bm, bl, kh, km};
+            const float hi[8] = {kl, kh, km, kh, sh, sm, sl, -1.0e30f};
+            uint16_t* o = &tb[((size_t)sg * HWp + t) * 16];
+            for (int e = 0; e < 8; ++e) {
+                o[e] = bf16_bits(lo[e]);
+                o[8 + e] = bf16_bits(hi[e]);
+            }
+            kq[(size_t)sg * HWp + t] = kqf;
+        }
+    }
+    if (!ctx->tc_b) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tc_b, tb.size() * 2));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->tc_kq, kq.size() * sizeof(float)));
+    } else {
+        HIP_TRY(ctx, hipDeviceSynchronize());      // a propagation in flight may still read the old constants
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->tc_b, tb.data(), tb.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->tc_kq, kq.data(), kq.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->tc_sig1 = sigma1;
+    ctx->tc_sig2 = sigma2;
+    ctx->tc_temp = temperature;
     return VOSPROP_OK;
 }
 
@@ -399,16 +459,7 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
         }
         return;
     }
-    // dense path: the in-wave pipelined kernel (prop_dense.h).  VOSPROP_DENSE_TWO_BURST=1 selects the round-1 two-burst schedule of
-    // prop_bf16.h (same results; A/B timing only)
-    static const bool two_burst = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
-    // the four-wave shape of the mask-only kernel (prop_wide.h) has the faster tile loop and the dearer segment start: measured in
-    // bench.py's loop it wins where a workgroup walks many tiles (720p, ~900 tile steps per workgroup: 814 against 826 us) and loses
-    // where it walks few (480p, 184 steps: 189 against 182 us; 240p: 30 against 26) - taken from 512 steps per workgroup up.
-    // VOSPROP_WIDE=0 / 1 forces either shape (A/B, tests).
-    static const int wide_env = getenv("VOSPROP_WIDE") ? atoi(getenv("VOSPROP_WIDE")) : -1;
-    const long long steps_per_wg = (long long)a.n_ref * a.tiles_per_frame * ((a.HWp + kBT - 1) / kBT) / (lp.grid > 0 ? lp.grid : 1);
-    const bool wide = wide_env >= 0 ? wide_env != 0 : steps_per_wg >= 512;
+    // dense path: the in-wave pipelined kernel (prop_dense.h); the mask-only label-mode step is the hand-ordered prop_mask_kernel
     if (lp.materialise) {   // the materialised-affinity variant: score tiles out to HBM, then back in (prop_dense.h MAT 1 / 2)
         if (lp.prob) {
             hipLaunchKernelGGL((prop_dense_kernel<true, true, 1>), grid, block, 0, s, a);
@@ -420,31 +471,16 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
         }
         return;
     }
-    if (!two_burst) {
-        if (lp.prob) {
-            if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<true, true>), grid, block, 0, s, a);
-            else hipLaunchKernelGGL((prop_dense_kernel<true, false>), grid, block, 0, s, a);
-        } else {
-            if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<false, true>), grid, block, 0, s, a);
-            else if (lp.no_l && wide) {      // the mask-only form in its four-wave shape (prop_wide.h)
-                const dim3 wblock(kWavesW * 64);
-                if (e0) hipExtLaunchKernelGGL(prop_wide_kernel, grid, wblock, 0, s, e0, e1, 0, a);
-                else hipLaunchKernelGGL(prop_wide_kernel, grid, wblock, 0, s, a);
-            } else if (lp.no_l) {
-                if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false, 0, false>), grid, block, 0, s, e0, e1, 0, a);
-                else hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false>), grid, block, 0, s, a);
-            } else if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, e0, e1, 0, a);
-            else hipLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, a);
-        }
-        return;
-    }
     if (lp.prob) {
-        if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<true, true, 0>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((prop_bf16_kernel<true, false, 0>), grid, block, 0, s, a);
+        if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((prop_dense_kernel<true, false>), grid, block, 0, s, a);
     } else {
-        if (lp.lab_lo) hipLaunchKernelGGL((prop_bf16_kernel<false, true, 0>), grid, block, 0, s, a);
-        else if (e0) hipExtLaunchKernelGGL((prop_bf16_kernel<false, false, 0>), grid, block, 0, s, e0, e1, 0, a);
-        else hipLaunchKernelGGL((prop_bf16_kernel<false, false, 0>), grid, block, 0, s, a);
+        if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<false, true>), grid, block, 0, s, a);
+        else if (lp.no_l) {      // the mask-only form (prop_mask.h)
+            if (e0) hipExtLaunchKernelGGL(prop_mask_kernel, grid, block, 0, s, e0, e1, 0, a);
+            else hipLaunchKernelGGL(prop_mask_kernel, grid, block, 0, s, a);
+        } else if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, e0, e1, 0, a);
+        else hipLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, a);
     }
 }
 
@@ -600,9 +636,13 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         lp.sel.thr_grp = ctx->tk_thr; lp.sel.thr_elem = ctx->tk_thr_elem; lp.sel.bitmap = ctx->tk_bitmap;
     }
     lp.materialise = ctx->cfg.materialise != 0;
-    static const bool keep_l = getenv("VOSPROP_KEEP_L") != nullptr;           // A/B: always accumulate the denominators
-    static const bool two_burst_l = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
-    lp.no_l = ctx->mask_only && !prob && !lab_lo && !topk && !f32 && !lp.materialise && !keep_l && !two_burst_l;
+    lp.no_l = ctx->mask_only && !prob && !lab_lo && !topk && !f32 && !lp.materialise && plan->steps_per_wg <= kMaskMaxSteps;
+    if (lp.no_l) {
+        rc = build_target_consts(ctx, sigma1, sigma2, temperature);
+        if (rc) return rc;
+        a.tc_b = ctx->tc_b;
+        a.tc_kq = ctx->tc_kq;
+    }
     if (lp.materialise) {
         if (f32 || topk) return fail(ctx, VOSPROP_E_UNSUPPORTED, "the materialised-affinity variant is dense, bf16 path only");
         const size_t need = (size_t)n_ref * ctx->tiles * ((size_t)ctx->TT * kWaves) * 64 * 16 * sizeof(bf16_t);
@@ -682,6 +722,8 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     st.hw = ctx->HW;
     st.workgroups = lp.grid;
     st.tiles_per_wg = (int)(((long long)ctx->TT * n_ref * ctx->tiles + lp.grid - 1) / lp.grid);
+    st.kernel_id = f32 ? VOSPROP_KERNEL_F32 : topk ? VOSPROP_KERNEL_TOPK : lp.materialise ? VOSPROP_KERNEL_MATERIALISED
+                   : lp.no_l ? VOSPROP_KERNEL_MASK : VOSPROP_KERNEL_DENSE;
     // ALGORITHMIC work, counted once whatever the number of passes the implementation makes: the top-k
     // variant scores every (reference, target) pair twice today, which is its cost, not its work
     st.flops = 2.0 * n_ref * HW * HW * kC + (topk ? 2.0 * d * topk * HW : 2.0 * d * n_ref * HW * HW);
@@ -947,6 +989,8 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     ring_free(ctx->ring);
     ring_free(ctx->scratch);
     if (ctx->coord_tab) (void)hipFree(ctx->coord_tab);
+    if (ctx->tc_b) (void)hipFree(ctx->tc_b);
+    if (ctx->tc_kq) (void)hipFree(ctx->tc_kq);
     if (ctx->coord_f32) (void)hipFree(ctx->coord_f32);
     if (ctx->up_tab) (void)hipFree(ctx->up_tab);
     if (ctx->part) (void)hipFree(ctx->part);
@@ -1081,10 +1125,9 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     // Channels-last bf16 features on the dense bf16 path are not copied into the ring up front: the propagation kernel reads the
     // target frame where the encoder left it and combine_kernel carries the copy (one launch and one dispatch gap fewer per frame)
     static const bool no_fuse_push = getenv("VOSPROP_FUSE_PUSH") && atoi(getenv("VOSPROP_FUSE_PUSH")) == 0;
-    static const bool two_burst_env = getenv("VOSPROP_DENSE_TWO_BURST") != nullptr;
     const bool hwc16 = feat_dtype == (VOSPROP_DT_BF16 | VOSPROP_LAYOUT_HWC) || feat_dtype == (VOSPROP_DT_F16 | VOSPROP_LAYOUT_HWC);
     const bool fuse_push = f > 0 && hwc16 && ctx->cfg.precision == VOSPROP_PREC_BF16 &&
-                           ctx->cfg.topk == 0 && !ctx->cfg.materialise && !no_fuse_push && !two_burst_env;
+                           ctx->cfg.topk == 0 && !ctx->cfg.materialise && !no_fuse_push;
     int rc = fuse_push ? VOSPROP_OK : push_features(ctx, feat_dev, feat_dtype, R, slot, s);
     if (rc) return rc;
     if (f == 0) {   // reference inference_utils.py:33-48: frame 0 only seeds the history
@@ -1161,6 +1204,17 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
                      out_dev, ctx->cls_tmp, nullptr, nullptr, s);
 }
 
+const char* vosprop_kernel_name(int kernel_id) {
+    switch (kernel_id) {
+        case VOSPROP_KERNEL_DENSE: return "prop_dense_kernel";
+        case VOSPROP_KERNEL_MASK: return "prop_mask_kernel";
+        case VOSPROP_KERNEL_TOPK: return "prop_dense_kernel<TK=1>+topk_select2_kernel+prop_dense_kernel<TK=2>";
+        case VOSPROP_KERNEL_F32: return "prop_f32_kernel";
+        case VOSPROP_KERNEL_MATERIALISED: return "prop_dense_kernel<MAT=1>+prop_dense_kernel<MAT=2>";
+        default: return "?";
+    }
+}
+
 int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out) {
     if (!ctx || !out) return VOSPROP_E_INVALID;
     if (!ctx->last.valid) return VOSPROP_E_STATE;
@@ -1213,6 +1267,32 @@ int vosprop_time_last_propagation(vosprop_ctx* ctx, int iters, void* stream, dou
     HIP_TRY(ctx, hipGetLastError());
     *mean_us = (double)ms * 1000.0 / iters;
     return VOSPROP_OK;
+}
+
+// Debug hook (not part of include/vosprop.h; tools/dbg_mask.py): re-run the last DENSE label-mode propagation with prop_mask_kernel
+// (which = 1) or prop_dense_kernel with denominators (which = 0) and copy the per-segment partials [n_parts][2 + d][256] to the host.
+// Both kernels walk the same segment table, so the two copies compare slot by slot.  Returns the number of floats.
+int vosprop_debug_partials(vosprop_ctx* ctx, int which, float* out_host, int max_floats) {
+    if (!ctx || !ctx->last.valid) return VOSPROP_E_STATE;
+    LastProp lp = ctx->last;
+    if (lp.topk || lp.prob || lp.lab_lo || lp.materialise || lp.args.feat_f32) return VOSPROP_E_UNSUPPORTED;
+    const Plan* plan = nullptr;
+    int rc = get_plan(ctx, lp.args.n_ref * ctx->tiles, &plan);
+    if (rc) return rc;
+    const size_t n = (size_t)plan->n_parts * lp.args.part_rows * kBT;
+    if ((size_t)max_floats < n) return VOSPROP_E_INVALID;
+    lp.no_l = which != 0;
+    if (lp.no_l) {
+        rc = build_target_consts(ctx, ctx->cfg.sigma1, ctx->cfg.sigma2, ctx->cfg.temperature);
+        if (rc) return rc;
+        lp.args.tc_b = ctx->tc_b;
+        lp.args.tc_kq = ctx->tc_kq;
+    }
+    HIP_TRY(ctx, hipMemset(ctx->part, 0, n * sizeof(float)));
+    launch_prop(ctx, lp, nullptr);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(out_host, ctx->part, n * sizeof(float), hipMemcpyDeviceToHost));
+    return (int)n;
 }
 
 #ifdef VOSPROP_STAMP

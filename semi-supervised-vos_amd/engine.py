@@ -172,7 +172,9 @@ class PropagationEngine:
     def last_stats(self):
         st = _native.Stats()
         self._check(self._L.vosprop_last_stats(self._ctx, ctypes.byref(st)), 'vosprop_last_stats')
-        return {k: getattr(st, k) for k, _ in st._fields_}
+        out = {k: getattr(st, k) for k, _ in st._fields_ if k != 'reserved_'}
+        out['kernel'] = self._L.vosprop_kernel_name(st.kernel_id).decode()      # what the engine launched (set where it decides)
+        return out
 
     def timing_begin(self):
         """Start bracketing every dense propagation-kernel launch with HIP events on its stream (in-situ timing)."""

@@ -482,9 +482,9 @@ def test_mask_only_step_at_full_480p_vs_oracle(vos, dev, peaky):
     assert len(np.unique(cls_hist[20])) >= 3        # the objects survive 20 propagations
 
 
-def test_mask_only_step_at_720p_takes_the_wide_kernel_and_matches_the_oracle(vos, dev):
-    """At 720p (90x160 map, N = 9: ~900 tile steps per workgroup) the engine launches the four-wave shape of the mask-only kernel by
-    itself (engine.hip launch_prop_mode: from 512 steps per workgroup up).  A 19-frame roll-out of mask-only steps; at frames 17
+def test_mask_only_step_at_720p_matches_the_oracle(vos, dev):
+    """720p (90x160 map, N = 9: ~500 tile steps per segment, eight control-table blocks): a 19-frame roll-out of mask-only steps -
+    the engine must report prop_mask_kernel as the kernel it launched (vosprop_stats.kernel_id, set where the launch is decided); at frames 17
     and 18 (frame_idx > 15: both sigma classes) the class map must be the arg-max of the oracle's predict_columns, fed with the
     engine's own label history, on every sampled column with a clear top-2 margin."""
     H, W = 720, 1280
@@ -514,6 +514,7 @@ def test_mask_only_step_at_720p_takes_the_wide_kernel_and_matches_the_oracle(vos
     st = eng.last_stats()
     eng.close()
     assert st['n_ref'] == 9 and st['hw'] == HW
+    assert st['kernel_id'] == vos._native.KERNEL_MASK and st['kernel'] == 'prop_mask_kernel', st
     onehot = np.zeros((d, T, HW), np.float32)
     for t in range(T):
         onehot[cls_hist[t], t, np.arange(HW)] = 1.0
@@ -528,17 +529,3 @@ def test_mask_only_step_at_720p_takes_the_wide_kernel_and_matches_the_oracle(vos
         checked += int(clear.sum())
     assert checked > 1000
     assert len(np.unique(cls_hist[18])) >= 3
-
-
-def test_wide_shape_of_the_mask_only_kernel_vs_oracle():
-    """prop_wide.h - the mask-only dense kernel as four waves x 64 columns, which the engine takes by itself only for large maps
-    (previous test): here forced with VOSPROP_WIDE=1 (read once per process, hence a child process) through the 480p oracle check
-    and the small mask-only cases."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, VOSPROP_WIDE='1')
-    r = subprocess.run([sys.executable, '-m', 'pytest', __file__, '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
-                        '-k', 'mask_only_step_at_full_480p_vs_oracle or rescale or edge'],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
