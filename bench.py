@@ -73,7 +73,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha1()
     src = ROOT / 'semi-supervised-vos_amd' / 'csrc'
-    for name in sorted(p.name for p in src.glob('prop_*.h')) + ['common.h', 'aux_kernels.h', 'engine.hip']:
+    for name in sorted(p.name for p in src.glob('prop_*'))      # (.h and the generated .inc) + ['common.h', 'aux_kernels.h', 'engine.hip']:
         h.update(name.encode())
         h.update((src / name).read_bytes())
     return h.hexdigest()[:12]
@@ -535,7 +535,7 @@ def main():
     traffic, traffic_src, pmc = None, None, {}
     prof = Path(__file__).resolve().parent / 'profiles'
     src_hash = kernel_source_hash()
-    tj = prof / f'r03_prop_kernel_traffic_{args.workload}.json'
+    tj = prof / f'r04_prop_kernel_traffic_{args.workload}.json'
     if tj.exists():
         try:
             t = json.loads(tj.read_text())
@@ -564,9 +564,8 @@ def main():
                        'step_form': 'mask only (pred_out_dev = NULL)', 'encoder_batch': B, 'encoder_weights': 'random-init, BatchNorm folded', 'objects': 3,
                        'videos_per_gpu': 1, 'sharding': 'whole videos per GPU, no collective'},
             'propagation_only_frames_per_s_per_gpu': prop_fps, 'encoder_us_per_frame': encoder_us, 'end_to_end': end_to_end,
-            'roofline': {'kernel': ('prop_dense_kernel<.,.,1> + <.,.,2> (affinity out to HBM, then back)' if hbm_bound else
-                                    'prop_dense_kernel<TK=1> + topk_select2_kernel + prop_dense_kernel<TK=2> (one scoring pass, select, re-score of the marked tiles)' if wl['topk'] else ('prop_wide_kernel (mask-only form, four waves x 64 columns)' if st['tiles_per_wg'] >= 512 and os.environ.get('VOSPROP_WIDE', '') != '0'
-                                     or os.environ.get('VOSPROP_WIDE', '') == '1' else 'prop_dense_kernel<mask-only form>')),
+            # the kernel the ENGINE reports it launched (vosprop_stats.kernel_id, set where the launch is decided) - never re-derived here
+            'roofline': {'kernel': st['kernel'], 'kernel_id': st['kernel_id'],
                          'bound': 'hbm' if hbm_bound else 'mfma', 'achieved': achieved_gbs if hbm_bound else achieved,
                          'peak': HBM_PEAK_GBS if hbm_bound else MFMA_BF16_PEAK_TFLOPS, 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
                          'frac': achieved_gbs / HBM_PEAK_GBS if hbm_bound else achieved / MFMA_BF16_PEAK_TFLOPS,

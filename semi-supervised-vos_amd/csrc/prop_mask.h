@@ -32,7 +32,10 @@
 #pragma once
 #include "common.h"
 #include "prop_bf16.h"
-#include "prop_mask_loop.inc"
+#ifndef VOSPROP_MASK_LOOP_INC
+#define VOSPROP_MASK_LOOP_INC "prop_mask_loop.inc"      // (tools/mask_variants.sh builds timing variants from other generator outputs)
+#endif
+#include VOSPROP_MASK_LOOP_INC
 
 namespace vosprop {
 
@@ -44,7 +47,8 @@ constexpr float kMaskAlarm = VOSPROP_MASK_ALARM;
 constexpr int kMaskTabBlock = VOSPROP_MASK_TAB_BLOCK;      // control-table entries a wave holds at a time (one per lane)
 constexpr int kMaskTabEntry = VOSPROP_MASK_TAB_ENTRY;      // bytes per entry in LDS
 constexpr int kMaskTabCap = 2048;                          // entries the LDS table holds: a segment may walk kMaskMaxSteps tiles
-constexpr int kMaskMaxSteps = kMaskTabCap - kMaskTabBlock - 3;      // (engine.hip falls back to prop_dense_kernel beyond that)
+constexpr int kMaskAhead = VOSPROP_MASK_AHEAD;             // tiles the LDS-DMA staging runs ahead of the scoring
+constexpr int kMaskMaxSteps = kMaskTabCap - kMaskTabBlock - kMaskAhead;      // (engine.hip falls back to prop_dense_kernel beyond that)
 static_assert(kMaskOffCoord == kLdsFeat && kMaskOffLab == kLdsFeat + kLdsCoord && kMaskSlot == kMaskOffLab + kLdsLab,
               "prop_mask_loop.inc and prop_bf16.h disagree on the slot layout");
 
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
     __shared__ __attribute__((aligned(16))) unsigned char smem[kMaskRing * kMaskSlot];
     __shared__ unsigned s_off[2 * kMaxRef];      // per sampled frame: byte offset of its slot in the feature ring / label ring
     // control table of the segment being walked, one entry per stream position: TA (feature-ring offset of the tile | flags of the
-    // tile two positions earlier), coordinate-table offset, label-ring offset, feature-ring offset
+    // tile kMaskAhead-1 positions earlier), coordinate-table offset, label-ring offset, feature-ring offset
     __shared__ __attribute__((aligned(16))) unsigned s_tab[kMaskTabCap * (kMaskTabEntry / 4)];
 
     const int tid = threadIdx.x;
@@ -149,14 +153,14 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
         const float kq1 = A.tc_kq[tq], kq2 = A.tc_kq[A.HWp + tq];
 
         // ---- control table of the segment -> LDS: entry of stream position p (clamped to the segment's last step):
-        //   TA = byte offset of the tile in the feature ring | flags of the tile TWO positions earlier (bit 0: it opens a pixel tile
+        //   TA = byte offset of the tile in the feature ring | flags of the tile kMaskAhead-1 positions earlier (bit 0: it opens a pixel tile
         //        or a sigma class - its LM must be built -, bit 1: its sigma class);  coordinate / label offsets of the tile
-        for (int p0 = tid_l; p0 < n_steps + kMaskTabBlock + 3; p0 += kWaves * 64) {
+        for (int p0 = tid_l; p0 < n_steps + kMaskTabBlock + kMaskAhead; p0 += kWaves * 64) {
             const int p = p0 < n_steps - 1 ? p0 : n_steps - 1;
             const int r = r_lo + p;
             const int tile = r / N, n = r - tile * N;
             const unsigned fo = s_off[n] + (unsigned)tile * (unsigned)kGlbFeat;
-            int p2 = p0 - 2;
+            int p2 = p0 - (kMaskAhead - 1);      // (step q reads entry q + kMaskAhead and wants the flags of tile q + 1)
             if (p2 > n_steps - 1) p2 = n_steps - 1;
             unsigned flags = 0;
             if (p2 >= 1) {
@@ -177,9 +181,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
         // stale LDS bits that happen to spell a NaN would turn 0 x NaN into the accumulators
         if (tid_l < kLdsLab / 16) *(f32x4*)(smem + (kMaskRing - 1) * kMaskSlot + kMaskOffLab + tid_l * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // ---- tiles 0, 1, 2 -> slots 0, 1, 2
+        // ---- tiles 0 .. kMaskAhead-1 -> slots 0 .. kMaskAhead-1
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < kMaskAhead; ++i) {
             const unsigned ea = (unsigned)__builtin_amdgcn_readlane((int)tab_a, i) & ~15u;
             const unsigned eb = (unsigned)__builtin_amdgcn_readlane((int)tab_b, i);
             const unsigned lds = smem_base + (unsigned)i * kMaskSlot;

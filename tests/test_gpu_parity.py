@@ -342,13 +342,18 @@ def test_mask_is_the_nearest_upsampling_of_the_class_map(vos, dev, H, W, topk):
     eng.close()
 
 
+@pytest.mark.parametrize('peaky', [False, True], ids=['n01_logits', 'peaky_logits'])
 @pytest.mark.parametrize('layout', ['nchw_f32', 'hwc_bf16'])
-def test_mask_only_steps_equal_steps_that_return_the_prediction(vos, dev, layout):
-    """A step that is not asked for the prediction runs the propagation kernel WITHOUT softmax denominators (they scale every
-    class of a column alike; prop_dense.h NEED_L = false), and with channels-last bf16 features it reads the target frame in
-    place while combine_kernel carries the ring copy.  A 24-frame roll-out (past frame 15: both sigmas; 9 references) must give
-    the masks of the roll-out that returns predictions (up to exact-tie pixels, see below), frame by frame, and peaky scores must
-    still trip the rescale path."""
+def test_mask_only_steps_equal_steps_that_return_the_prediction(vos, dev, layout, peaky):
+    """A step that is not asked for the prediction runs prop_mask_kernel (no softmax denominators: they scale every class of a
+    column alike; c = temperature log2(e) folded into the target fragments, T' = bf16(c T)), and with channels-last bf16 features it
+    reads the target frame in place while combine_kernel carries the ring copy.  A 24-frame roll-out (past frame 15: both sigmas; 9
+    references) must stay with the roll-out that returns predictions (prop_dense_kernel), frame by frame.  The two kernels are two
+    roundings of the same sums - the mask kernel's target features carry one more bf16 rounding (2^-9 relative) - so near-tie pixels
+    may fall either way and then feed back through the labels: <= 0.5 % of the pixels (the bf16 path's stated mask tolerance) on
+    N(0,1) logits; `peaky` (every fifth frame x6: logit sigma ~36 on those pairs, which trips the rescale path again and again) turns
+    2^-9 into logit differences of ~0.1 on salt-and-pepper labels: <= 2 % there.  What PINS each kernel is the oracle
+    (test_mask_only_step_at_full_480p_vs_oracle for this one)."""
     H, W = 120, 214
     Hd, Wd = vos.feature_map_size(H, W)
     rs = np.random.RandomState(77)
@@ -357,7 +362,7 @@ def test_mask_only_steps_equal_steps_that_return_the_prediction(vos, dev, layout
     ann[60:110, 100:200] = 2
     feats = []
     for t in range(24):
-        f = torch.from_numpy(rs.randn(256, Hd, Wd).astype(np.float32) * (0.25 if t % 5 else 1.5)).to(dev)
+        f = torch.from_numpy(rs.randn(256, Hd, Wd).astype(np.float32) * (0.25 if (t % 5 or not peaky) else 1.5)).to(dev)
         if layout == 'hwc_bf16':
             f = f.to(torch.bfloat16)[None].contiguous(memory_format=torch.channels_last)[0]
         feats.append(f)
@@ -374,12 +379,8 @@ def test_mask_only_steps_equal_steps_that_return_the_prediction(vos, dev, layout
         eng.close()
         masks[want_pred] = out
     assert len(masks[True]) == len(masks[False]) == 23
-    # [r3] the two forms are different roundings of the same sum (the mask-only form folds the prior into the exponent: one
-    # exponential per score, prop_dense.h), so a pixel whose two best classes tie to ~1e-5 relative may fall either way - and then
-    # feeds back through the labels.  What pins each form is the ORACLE (test_mask_only_step_at_full_480p_vs_oracle for this one);
-    # here: the roll-outs stay together.
     worst = max(float((a != b).float().mean()) for a, b in zip(masks[True], masks[False]))
-    assert worst <= 2e-3, worst
+    assert worst <= (2e-2 if peaky else 5e-3), worst
     assert len({int(m.sum()) for m in masks[False]}) > 1
 
 

@@ -71,6 +71,7 @@ S_BA = 88               # s[88:89] feature base + tile offset
 S_BC = 90               # s[90:91] third-piece base + tile offset
 TAB_ENTRY = 16          # bytes per control-table entry in LDS: TA, coordinate offset, label offset, pad
 TAB_BLOCK = 64
+AHEAD = 3               # default look-ahead of the LDS-DMA staging in tiles (option 'ahead': 3 or 4 with the six-slot ring)
 
 HAZ_MFMA_TO_VALU = 12   # 8-pass MFMA result -> VALU read/write, or -> MFMA operand other than "same accumulator as C"
 HAZ_VALU_TO_MFMA = 2    # VALU-written VGPR -> MFMA A/B operand
@@ -136,33 +137,66 @@ def lane_addr(slot, off):
 
 def gen_step(st, k, tag):
     """Step copy k (tile q = k mod 6)."""
-    cur, nxt, prv, stg = k, (k + 1) % NSLOT, (k + 5) % NSLOT, (k + 3) % NSLOT
+    ahead = st.opts.get('ahead', AHEAD)
+    cur, nxt, prv, stg = k, (k + 1) % NSLOT, (k + 5) % NSLOT, (k + ahead) % NSLOT
     S, P = V_S[k % 2], V_S[(k + 1) % 2]
     pk_w, pk_r = V_PK[(k + 1) % 2], V_PK[k % 2]
     o = st.opts
     e = st.emit
 
+    ab = o.get('ablate', ())      # timing experiments only (results are garbage): tools/mask_ablate.sh
+
     def mfma(dst, a, b, c, reads_extra=()):
+        if 'no_mfma' in ab and dst in V_S:
+            return
+        if 'no_lab' in ab and dst == V_Y:
+            return
+        if 'm16' in ab and dst in V_S:
+            # timing experiment: the same MACs as two v_mfma_f32_16x16x32_bf16 (4-register accumulators; results are garbage)
+            for half in range(2):
+                d4 = vr(dst + 4 * half, 4)
+                e(f'v_mfma_f32_16x16x32_bf16 {d4}, {vr(a, 4)}, {vr(b, 4)}, {d4}', 'mfma', reads=set(regs(a, 4)) | set(regs(b, 4)),
+                  writes=regs(dst + 4 * half, 4))
+            return
         ctext = '0' if c is None else vr(c, 16)
         rd = set(regs(a, 4)) | set(regs(b, 4)) | (set(regs(c, 16)) if c is not None else set())
         e(f'v_mfma_f32_32x32x16_bf16 {vr(dst, 16)}, {vr(a, 4)}, {vr(b, 4)}, {ctext}', 'mfma', reads=rd, writes=regs(dst, 16))
 
     def vexp(q, r):
+        if 'no_valu' in ab:
+            return
         e(f'v_exp_f32 v{V_Q + q}, v{P + r}', 'trans', reads=[P + r], writes=[V_Q + q])
 
     def vcvt(i, qa, qb):
+        if 'no_valu' in ab:
+            return
         e(f'v_cvt_pk_bf16_f32 v{pk_w + i}, v{V_Q + qa}, v{V_Q + qb}', 'valu', reads=[V_Q + qa, V_Q + qb], writes=[pk_w + i])
 
     def vmax(i):
+        if 'no_valu' in ab:
+            return
         if i == 0:
             e(f'v_max_f32 v{V_MX}, v{P}, v{P + 1}', 'valu', reads=[P, P + 1], writes=[V_MX])
         else:
             e(f'v_max3_f32 v{V_MX}, v{V_MX}, v{P + 2 * i}, v{P + 2 * i + 1}', 'valu', reads=[V_MX, P + 2 * i, P + 2 * i + 1], writes=[V_MX])
 
-    def piece(m0_base, m0_imm, src, base):
+    def piece_args(i):
+        if i == 0:
+            return '%[ldsa]', stg * SLOT, V_SRCA, S_BA
+        if i == 1:
+            return '%[ldsa]', stg * SLOT + 8192, V_SRCB, S_BA
+        return '%[lds3]', stg * SLOT, V_SRC3, S_BC
+
+    def piece_m0(i):          # M0 = LDS destination; written ahead of the gap's MFMA so that no s_nop is needed in front of the DMA
+        if 'no_dma' in ab:
+            return
+        m0_base, m0_imm, _, _ = piece_args(i)
         e(f's_add_u32 m0, {m0_base}, {m0_imm}', 'm0')
-        if o.get('m0_nop', True):
-            e('s_nop 0', 'nop')
+
+    def piece_dma(i):
+        if 'no_dma' in ab:
+            return
+        _, _, src, base = piece_args(i)
         e(f'global_load_lds_dwordx4 v{src}, s[{base}:{base + 1}]', 'dma', reads=[src])
 
     # ---- boundary ----
@@ -179,7 +213,10 @@ def gen_step(st, k, tag):
     npieces = st.role_pieces
     dma_gaps = o.get('dma_gaps', {3: [4, 8, 12], 2: [5, 11]})[npieces]
 
+    bar_gap = o.get('skew_gap', 7) if (o.get('skew', True) and npieces == 2) else 15
     for g in range(16):
+        if g in dma_gaps:
+            piece_m0(dma_gaps.index(g))
         # the fragment this MFMA consumes
         st.wait_for(f'A{g & 7}')
         mfma(S, V_A + 4 * (g & 7), V_B + 4 * g, V_LM if g == 0 else S)
@@ -187,7 +224,8 @@ def gen_step(st, k, tag):
             reg, off = row_addr(cur, g + 8)
         else:
             reg, off = row_addr(nxt, g - 8)
-        st.ds_read(f'A{g & 7}', V_A + 4 * (g & 7), 4, reg, off)
+        if 'no_ds' not in ab:
+            st.ds_read(f'A{g & 7}', V_A + 4 * (g & 7), 4, reg, off)
         if g == 0:
             e(f'v_readlane_b32 s{S_RAWA}, v{V_TA}, s{S_IDX}', 'valu')
             if npieces == 3:
@@ -209,13 +247,7 @@ def gen_step(st, k, tag):
             reg, off = lane_addr(nxt, OFF_COORD)
             st.ds_read('CA', V_CA, 4, reg, off)
         if g in dma_gaps:
-            i = dma_gaps.index(g)
-            if i == 0:
-                piece('%[ldsa]', stg * SLOT, V_SRCA, S_BA)
-            elif i == 1:
-                piece('%[ldsa]', stg * SLOT + 8192, V_SRCB, S_BA)
-            else:
-                piece('%[lds3]', stg * SLOT, V_SRC3, S_BC)
+            piece_dma(dma_gaps.index(g))
         for r in exp_rows.get(g, []):
             vexp(r % 4, r)
         if g in max_at:
@@ -225,7 +257,9 @@ def gen_step(st, k, tag):
             vcvt(i, (2 * i) % 4, (2 * i + 1) % 4)
         if g == 9:
             e(f'v_cmp_lt_f32_e32 vcc, 0x{float_bits(ALARM):08x}, v{V_MX}', 'valu', reads=[V_MX])
-        if g == 10:
+        if g == 10 and 'no_lm' in ab:
+            st.wait_for('CA')
+        if g == 10 and 'no_lm' not in ab:
             # tile q+1 opens a pixel tile or a sigma class: its prior tile LM = coordinates x target-side constants (one MFMA)
             st.wait_for('CA')
             e(f's_bitcmp1_b32 s{S_RAWA}, 0', 's')
@@ -237,15 +271,20 @@ def gen_step(st, k, tag):
             st.label(f'LV{k}_{tag}')
             mfma(V_LM, V_CA, V_CB[1], None)
             st.label(f'LW{k}_{tag}')
-        if g == 12:
+        if g == 12 and 'no_lab' not in ab:
             reg, off = lane_addr(prv, OFF_LAB)
             st.ds_read('LAB0', V_LAB, 4, reg, off)
-        if g == 13:
+        if g == 13 and 'no_lab' not in ab:
             reg, off = lane_addr(prv, OFF_LAB + 1024)
             st.ds_read('LAB1', V_LAB + 4, 4, reg, off)
-    # ---- step end: own pieces of tile q+2 (issued in step q-1) have landed; the barrier publishes every wave's ----
-    e(f's_waitcnt vmcnt({npieces})', 'wait')
-    e('s_barrier', 'barrier')
+        if g == bar_gap:
+            # own pieces of tile q+2 (issued in step q+2-ahead) have landed, younger ones fly on; the barrier publishes every wave's.
+            # (Role B with 'skew': in the middle of its step - the two waves of a SIMD then sit half a step apart.)
+            issued = sum(1 for x in dma_gaps if x <= g)
+            if 'no_dma' not in ab:
+                e(f's_waitcnt vmcnt({npieces * (ahead - 3) + issued})', 'wait')
+            if 'no_barrier' not in ab:
+                e('s_barrier', 'barrier')
 
 
 def float_bits(x):
@@ -333,6 +372,7 @@ def gen_role(tag, npieces, opts):
     check_hazards(st.ins, start)
     thr = f'0x{float_bits(ALARM):08x}'
     neg_inf = '0xff800000'
+    ahead = opts.get('ahead', AHEAD)
     init = []
     for r in range(16):
         init += [f'v_mov_b32_e32 v{V_Y + r}, 0', f'v_mov_b32_e32 v{V_PK[0] + r}, 0', f'v_mov_b32_e32 v{V_S[1] + r}, {neg_inf}']
@@ -346,6 +386,10 @@ def gen_role(tag, npieces, opts):
     init += ['s_waitcnt lgkmcnt(0)', f's_cmp_lg_u32 %[sp0], 0', f's_cbranch_scc1 LI2_{tag}',
              f'v_mfma_f32_32x32x16_bf16 {vr(V_LM, 16)}, {vr(V_CA, 4)}, {vr(V_CB[0], 4)}, 0', f's_branch LI3_{tag}', f'LI2_{tag}:',
              f'v_mfma_f32_32x32x16_bf16 {vr(V_LM, 16)}, {vr(V_CA, 4)}, {vr(V_CB[1], 4)}, 0', f'LI3_{tag}:', 's_nop 7', 's_nop 7']
+    if opts.get('prio_b') is not None and npieces == 2:
+        init.append(f"s_setprio {opts['prio_b']}")
+    if opts.get('prio_a') is not None and npieces == 3:
+        init.append(f"s_setprio {opts['prio_a']}")
     head = init + [
         # ---- segment state ----
         f's_mov_b32 s{S_Q}, 0', f's_mov_b32 s{S_PHASE}, 0', f's_mov_b32 s{S_TBASE}, 0', f's_mov_b32 s{S_CENT}, 0',
@@ -357,13 +401,13 @@ def gen_role(tag, npieces, opts):
         f's_sub_u32 s{S_WD}, s{S_WD}, 1',          # (bounded: the loop can never spin, whatever else is wrong)
         f's_cbranch_scc1 LDONE_{tag}',
         f's_sub_u32 s{S_CNT}, %[n], s{S_Q}',
-        f's_add_u32 s{S_TMP}, s{S_TBASE}, {TAB_BLOCK - 3}',
+        f's_add_u32 s{S_TMP}, s{S_TBASE}, {TAB_BLOCK} - {ahead}',
         f's_sub_u32 s{S_TMP}, s{S_TMP}, s{S_Q}',
         f's_min_u32 s{S_CNT}, s{S_CNT}, s{S_TMP}',
         f's_cmp_eq_u32 s{S_CENT}, 0',
         f's_cselect_b32 s{S_TMP}, 2, s{S_CNT}',
         f's_min_u32 s{S_CNT}, s{S_CNT}, s{S_TMP}',
-        f's_add_u32 s{S_IDX}, s{S_Q}, 3',
+        f's_add_u32 s{S_IDX}, s{S_Q}, {ahead}',
         f's_sub_u32 s{S_IDX}, s{S_IDX}, s{S_TBASE}',
         's_mov_b64 vcc, 0',
         's_nop 3',
@@ -377,7 +421,7 @@ def gen_role(tag, npieces, opts):
         # ---- a step boundary: q steps are done, tile q-2 is pending (alarm decided, label product not run) ----
         f'LEXIT_{tag}:', 's_waitcnt lgkmcnt(0)', 's_nop 7', 's_nop 7',
         f's_add_u32 s{S_Q}, s{S_IDX}, s{S_TBASE}',
-        f's_sub_u32 s{S_Q}, s{S_Q}, 3',
+        f's_sub_u32 s{S_Q}, s{S_Q}, {ahead}',
         f's_cmp_lt_u32 s{S_Q}, 2',
         f's_cbranch_scc1 LNOPEND_{tag}',
         f's_cmp_eq_u32 s{S_CENT}, 0',
@@ -395,11 +439,11 @@ def gen_role(tag, npieces, opts):
         f'LNOPEND_{tag}:',
         f's_cmp_ge_u32 s{S_Q}, %[n]',
         f's_cbranch_scc1 LDONE_{tag}',
-        f's_add_u32 s{S_TMP}, s{S_TBASE}, {TAB_BLOCK - 3}',
+        f's_add_u32 s{S_TMP}, s{S_TBASE}, {TAB_BLOCK} - {ahead}',
         f's_cmp_lt_u32 s{S_Q}, s{S_TMP}',
         f's_cbranch_scc1 LCTL_{tag}',
         # ---- the next 64 control-table entries (built by the prologue in LDS) ----
-        f's_add_u32 s{S_TBASE}, s{S_Q}, 3',
+        f's_add_u32 s{S_TBASE}, s{S_Q}, {ahead}',
         f's_mul_i32 s{S_TMP}, s{S_TBASE}, {TAB_ENTRY}',
         f's_add_u32 s{S_TMP}, s{S_TMP}, %[tab]',
         f'v_add_u32_e32 v{TEMPS[0]}, s{S_TMP}, v{V_TABA}',
@@ -520,6 +564,7 @@ def render(opts):
     out.append(f'#define VOSPROP_MASK_AUX_MC {V_MC - V_AUX}')
     out.append(f'#define VOSPROP_MASK_TAB_ENTRY {TAB_ENTRY}')
     out.append(f'#define VOSPROP_MASK_TAB_BLOCK {TAB_BLOCK}')
+    out.append(f"#define VOSPROP_MASK_AHEAD {opts.get('ahead', AHEAD)}")
     clob = [f'v{i}' for i in list(range(V_LM, V_LM + 16)) + list(range(V_A, V_A + 32)) + list(range(V_CA, V_CA + 8))]
     clob += [f's{i}' for i in range(S_Q, S_BC + 2)]
     out.append('#define VOSPROP_MASK_CLOBBERS ' + ', '.join(f'"{c}"' for c in clob) + ', "vcc", "scc", "memory"')
@@ -534,8 +579,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check', action='store_true')
     ap.add_argument('--out', default=str(OUT))
+    ap.add_argument('--ablate', default='', help='comma list of no_dma,no_barrier,no_valu,no_ds,no_lab,no_mfma,no_lm (timing experiments: WRONG results)')
+    ap.add_argument('--opt', action='append', default=[], help='key=value generator options (python literals)')
     args = ap.parse_args()
-    text = render({})
+    opts = {'ablate': tuple(x for x in args.ablate.split(',') if x)}
+    for kv in args.opt:
+        k, v = kv.split('=', 1)
+        import ast
+        opts[k] = ast.literal_eval(v)
+    text = render(opts)
     if args.check:
         cur = Path(args.out).read_text() if Path(args.out).exists() else ''
         if cur != text:

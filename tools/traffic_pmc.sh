@@ -2,7 +2,7 @@
 # HBM-side traffic of the propagation kernel(s) of one workload: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes, as
 # MI355X_MICROARCH.md prescribes (plus GRBM_GUI_ACTIVE, TCC hit / miss).  Usage (on the GPU box):
 #     bash tools/traffic_pmc.sh <tag> [prop_bench args]        e.g.  bash tools/traffic_pmc.sh davis480p_r50_dense --stateful
-# Writes gpurun_out/traffic_<tag>/{summary.txt,traffic.json} (copy the json to profiles/r03_prop_kernel_traffic_<tag>.json;
+# Writes gpurun_out/traffic_<tag>/{summary.txt,traffic.json} (copy the json to profiles/r04_prop_kernel_traffic_<tag>.json;
 # it carries the hash of the kernel sources it was taken with - bench.py quotes it only while that hash matches the build).
 R=$(cd "$(dirname "$0")/.." && pwd)
 tag=$1; shift
