@@ -73,7 +73,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha1()
     src = ROOT / 'semi-supervised-vos_amd' / 'csrc'
-    for name in sorted(p.name for p in src.glob('prop_*'))      # (.h and the generated .inc) + ['common.h', 'aux_kernels.h', 'engine.hip']:
+    for name in sorted(p.name for p in src.glob('prop_*')) + ['common.h', 'aux_kernels.h', 'engine.hip']:      # (prop_*: .h and the generated .inc)
         h.update(name.encode())
         h.update((src / name).read_bytes())
     return h.hexdigest()[:12]

@@ -110,8 +110,6 @@ struct PropArgs {
     // prop_mask_kernel (prop_mask.h): target-side constants of the prior MFMA, built once per engine (engine.hip build_target_consts)
     const void* tc_b;           // [2 sigma][HWp][2 k halves] bf16x8: B fragment of the prior MFMA with c folded in and the 3-way split of -g Q_t c
     const float* tc_kq;         // [2 sigma][HWp] g Q_t c
-    int no_skew;                // dense kernel: 1 = both waves of a SIMD keep their barrier at the step end (VOSPROP_DENSE_SKEW=0, A/B only)
-    unsigned long long* dbg;    // diagnostic builds only (-DVOSPROP_STAMP): per-wave cycle sums; else nullptr
 };
 
 }  // namespace vosprop

@@ -273,7 +273,7 @@ int ensure_part(vosprop_ctx* ctx, size_t bytes) {
 // partial slots that will hold it.  Cached per NT; built on first use (a few microseconds of host work).
 // Pure host function: the segment lists of every workgroup (index b = i * 8 + x runs on XCD x) for TT target tiles and NT
 // reference tiles.  Returns the workgroups per XCD.
-int build_segments(int TT, int NT, bool streamk, std::vector<std::vector<Segment>>& per_wg) {
+int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
     long long per_xcd = ((long long)TT * NT + kXcd - 1) / kXcd;
     long long Iq = per_xcd / 4;   // at least ~4 tile steps per workgroup
     const int I = (int)(Iq < 1 ? 1 : (Iq > 32 ? 32 : Iq));
@@ -285,21 +285,6 @@ int build_segments(int TT, int NT, bool streamk, std::vector<std::vector<Segment
         const int r0 = (int)((long long)x * NT / kXcd), r1 = (int)((long long)(x + 1) * NT / kXcd);
         const int RX = r1 - r0;
         if (RX <= 0) continue;
-        if (streamk) {
-            const long long Q = (long long)TT * RX;
-            for (int i = 0; i < I; ++i) {
-                long long q = Q * i / I;
-                const long long q1 = Q * (i + 1) / I;
-                while (q < q1) {
-                    const int tt = (int)(q / RX);
-                    long long qe = (long long)(tt + 1) * RX;
-                    if (qe > q1) qe = q1;
-                    add(x, i, tt, r0 + (int)(q - (long long)tt * RX), (int)(qe - q));
-                    q = qe;
-                }
-            }
-            continue;
-        }
         // lockstep map: k full rounds (workgroup i takes target tile j*I + i over the whole part), then the leftover tiles
         const int k = TT / I, rem = TT - k * I;
         for (int j = 0; j < k; ++j)
@@ -345,10 +330,8 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
     Plan p;
     p.NT = NT;
     const int TT = ctx->TT;
-    static const char* map_env = getenv("VOSPROP_MAP");   // "streamk": the round-1 map (contiguous shares, experiments only)
-    const bool streamk = map_env && std::string(map_env) == "streamk";
     std::vector<std::vector<Segment>> per_wg;
-    p.wg_per_xcd = build_segments(TT, NT, streamk, per_wg);
+    p.wg_per_xcd = build_segments(TT, NT, per_wg);
     p.grid = kXcd * p.wg_per_xcd;
     // Partial slots are numbered so that the slots of one target tile are CONSECUTIVE: slot = off[tt] + (its rank among the tile's
     // segments).  The kernels that merge partials then need `off` only - the slot list is the identity and they do not load it (one
@@ -433,9 +416,7 @@ int push_features(vosprop_ctx* ctx, const void* src, int dtype, Ring& r, int slo
 void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStream_t s, hipEvent_t e0 = nullptr,
                       hipEvent_t e1 = nullptr) {
     const dim3 grid(lp.grid), block(kWaves * 64);
-    static const bool no_skew = getenv("VOSPROP_DENSE_SKEW") && atoi(getenv("VOSPROP_DENSE_SKEW")) == 0;
-    PropArgs a = a_in;
-    a.no_skew = no_skew ? 1 : 0;
+    const PropArgs& a = a_in;
     if (mode == 1) {      // top-k pass 1 (list partials): one instantiation per list length
         switch (lp.tk_ks) {
             case 8: hipLaunchKernelGGL((prop_dense_kernel<false, false, 0, false, 1, 8>), grid, block, 0, s, a); break;
@@ -711,9 +692,6 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         a.target_f16 = 0;
     }
     HIP_TRY(ctx, hipGetLastError());
-#ifdef VOSPROP_STAMP
-    lp.args.dbg = nullptr;   // set by vosprop_debug_stamps
-#endif
     lp.valid = true;
     ctx->last = lp;
     vosprop_stats& st = ctx->stats;
@@ -903,9 +881,9 @@ int vosprop_debug_topk(vosprop_ctx* ctx, float* thr_grp, float* thr_elem, int* g
 }
 
 /* test hook (no GPU needed): segment table for TT target tiles x NT reference tiles; rows of out = (workgroup, tt, r_lo, n_steps) */
-int vosprop_debug_plan(int TT, int NT, int streamk, int* out, int cap_rows) {
+int vosprop_debug_plan(int TT, int NT, int* out, int cap_rows) {
     std::vector<std::vector<Segment>> per_wg;
-    build_segments(TT, NT, streamk != 0, per_wg);
+    build_segments(TT, NT, per_wg);
     int n = 0;
     for (size_t b = 0; b < per_wg.size(); ++b)
         for (const Segment& sg : per_wg[b]) {
@@ -1294,25 +1272,5 @@ int vosprop_debug_partials(vosprop_ctx* ctx, int which, float* out_host, int max
     HIP_TRY(ctx, hipMemcpy(out_host, ctx->part, n * sizeof(float), hipMemcpyDeviceToHost));
     return (int)n;
 }
-
-#ifdef VOSPROP_STAMP
-// Diagnostic builds only (not part of include/vosprop.h): re-run the last propagation with in-kernel s_memtime stamps and
-// return, per wave, the cycle sums of the VOSPROP_NSTAMP loop segments.  out_host: [grid*8*VOSPROP_NSTAMP] u64.
-int vosprop_debug_stamps(vosprop_ctx* ctx, unsigned long long* out_host, int max_words) {
-    if (!ctx || !ctx->last.valid) return VOSPROP_E_STATE;
-    const size_t n = (size_t)ctx->last.grid * kWaves * VOSPROP_NSTAMP;
-    if ((size_t)max_words < n) return VOSPROP_E_INVALID;
-    unsigned long long* d = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&d, n * 8));
-    HIP_TRY(ctx, hipMemset(d, 0, n * 8));
-    LastProp lp = ctx->last;
-    lp.args.dbg = d;
-    launch_prop(ctx, lp, nullptr);
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipMemcpy(out_host, d, n * 8, hipMemcpyDeviceToHost));
-    (void)hipFree(d);
-    return (int)n;
-}
-#endif
 
 }  // extern "C"

@@ -1,7 +1,8 @@
-// The dense propagation kernel, software-pipelined INSIDE the wave (the shipped hot kernel for topk == 0).
+// The dense propagation kernel, software-pipelined INSIDE the wave: every dense form that keeps the softmax denominators (a
+// prediction was requested, probability mode), both top-k passes and the materialised-affinity variant.  The plain mask-only step
+// of the frame loop - the kernel bench.py times - is prop_mask_kernel (prop_mask.h), a hand-ordered stream of the same arithmetic.
 //
-// Same arithmetic, LDS layout, work decomposition and partial format as prop_bf16.h (which keeps the two top-k passes), another
-// schedule.  What the round-2 stamps of the two-burst kernel showed (profiles/r02_*): with a wave in its MFMA burst and its SIMD
+// Arithmetic helpers, LDS layout constants and LDS-DMA pieces live in prop_bf16.h.  What the round-2 stamps of the two-burst kernel showed (profiles/r02_*): with a wave in its MFMA burst and its SIMD
 // partner in its softmax burst, BOTH bursts take ~900 cycles - the sum of what they take alone (~600 + ~300): two waves of one SIMD
 // do not overlap matrix and vector work, while up to five single-issue VALU instructions DO hide in the 32-cycle shadow of an MFMA
 // of the SAME wave (tools/ubench_issue.hip; MI355X_MICROARCH "issue cost" rows).  So here every wave runs ONE continuous stream:
@@ -23,18 +24,8 @@
 #include "common.h"
 #include "prop_bf16.h"
 
-#ifndef VOSPROP_DABLATE
-#define VOSPROP_DABLATE 0   // timing experiments only (tools/dense_ablate.sh; results are WRONG by construction): 1 = no softmax VALU in
-                            // the chain, 2 = no LDS fragment refills, 4 = no staging, 8 = no per-step barrier, 16 = no score MFMAs, 32 = no label MFMAs, 64 = no prior tiles
-#endif
 
-// prop_wide.h lays the rare paths of its tile loop (rescale, tail tile, table refill) out of the loop's straight line.  (Measured on
-// this kernel too: 197-201 us with the hint on its three rare branches against 195-199 without - left as hipcc places them.)
-#ifndef VOSPROP_NO_EXPECT
 #define VOSPROP_UNLIKELY(x) __builtin_expect(!!(x), 0)
-#else
-#define VOSPROP_UNLIKELY(x) (x)
-#endif
 
 namespace vosprop {
 
@@ -105,6 +96,7 @@ template <bool PROB, bool LAB_LO, int MAT = 0, bool NEED_L = true, int TK = 0, i
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropArgs A) {
     static_assert(NEED_L || (!PROB && !LAB_LO && MAT == 0), "denominators may only be dropped in plain label mode");
     static_assert(TK == 0 || (!PROB && !LAB_LO && MAT == 0 && !NEED_L), "the top-k passes are label-mode, mask-only forms");
+    static_assert(NEED_L || TK != 0, "the plain mask-only step is prop_mask_kernel (prop_mask.h); NEED_L = false remains for the top-k passes");
     __shared__ __attribute__((aligned(16))) unsigned char smem[kRing5 * kLdsBuf];
     __shared__ __attribute__((aligned(16))) bf16x8 s_bx[2][kWaves * 64];   // per-lane prior constants (see prop_bf16.h)
     __shared__ float s_kq[2][kWaves * 64];
@@ -138,11 +130,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
     // feature pieces w, w+4, w+8, w+12 and the fifth by the table above.  The older wave wins every issue arbitration and then waits
     // at the barrier for its younger partner (stamps: ~550 cycles per step); the staging instructions are work that can move from the
     // wave that sets the step time to the wave that has slack.
-#ifdef VOSPROP_STAGE_ALL      // A/B build: every wave stages three pieces (the mid-round scheme)
-    constexpr bool kStageA = false;
-#else
     constexpr bool kStageA = MAT == 0 && !LAB_LO;
-#endif
     const unsigned src_a = feat_src_off(wave), src_b = feat_src_off(kStageA ? wave + 4 : wave + 8);
     const unsigned src_c = feat_src_off(wave + 8), src_d = feat_src_off(wave + 12);   // kStageA only
     const size_t feat_slot_stride = (size_t)A.HWp * (kC * 2);
@@ -192,11 +180,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
     if (TK == 1) {      // pass 1 also clears the bitmaps topk_select2_kernel will mark (it runs after this kernel on the stream)
         for (int i = blockIdx.x * (kWaves * 64) + tid; i < A.tk_bitmap_words; i += gridDim.x * (kWaves * 64)) A.tk_bitmap[i] = 0u;
     }
-#ifdef VOSPROP_STAMP
-    unsigned long long t_seg = 0, rt0 = 0;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");   // 100 MHz wall clock: launch ramp / tail
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_seg)::"memory");
-#endif
     for (int si = seg0; si < seg1; ++si) {
         Segment sg;
         if (TK == 2) {
@@ -248,11 +231,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);
         const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
         const int part_slot = __builtin_amdgcn_readfirstlane(sg.slot);
-        STAMP_DECL;
-#ifdef VOSPROP_STAMP
-        tprev = t_seg;
-        STAMP_AT(12);   // 12: the segment record (and the previous segment's partial stores being issued)
-#endif
 
         // What a segment start computes from the thread id is computed HERE, from an opaque copy: as loop invariants hoisted above
         // the segment loop these values were spilled around the tile loop (256 registers) and every reload brought an
@@ -311,10 +289,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) Wt[r] = 0.0f;
         constexpr bool FUSED = !NEED_L;
-#ifndef VOSPROP_ROWS_EARLY
-#define VOSPROP_ROWS_EARLY 1      // A/B switch of the row schedule below (step lambda)
-#endif
-        constexpr bool kRowsEarly = FUSED && TK == 0 && VOSPROP_ROWS_EARLY != 0;
+        constexpr bool kRowsEarly = FUSED && TK == 0;
         bool w_sparse = false;      // sigma class Wt was built with (FUSED: the rescale path rebuilds LM against the new max)
 
         // ---- staging cursor (frame inner) and the three pieces of a tile ----
@@ -401,9 +376,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         // the target fragments are "used" HERE: their loads (issued first) fly under the prior-constant arithmetic and the staging of
         // the first three tiles, one memory latency per segment start instead of two - and hipcc's waits for them stay out of the
         // tile loop
-#ifdef VOSPROP_STAMP
-        STAMP_AT(13);   // 13: issue of the target-fragment loads, prior constants, staging of the first three tiles
-#endif
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) asm volatile("" : "+v"(Bt[ks]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -417,16 +389,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 for (int e = 0; e < 8; ++e) Bt[ks][e] = (bf16_t)(float)hv[e];
             }
         }
-#ifdef VOSPROP_STAMP
-        STAMP_AT(14);   // 14: wait for all of it
-#endif
         __syncthreads();
 
-#ifdef VOSPROP_STAMP
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-        tsum[7] += tprev - t_seg;   // 7: segment prologue (target fragments, prior constants, first three tiles)
-        tsum[10] += 1;              // 10: segments
-#endif
         // compute cursor (pixel tile, frame) of the tile whose SCORES are being computed
         int ctile = r_lo / N, cn = r_lo - ctile * N;
         int cidx = 0;      // TK 2: position of the compute cursor in the walk list
@@ -489,11 +453,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 softmax_rows<PROB, FUSED>(Sp, Wt, c, mn * c, lt0, lt1, pk0, pk1);
             }
             if (NEED_L) st.l += lt0 + lt1;
-#if !(VOSPROP_DABLATE & 32)
             label_mfmas<LAB_LO>(labp, pk0, pk1, st.Y);
-#else
-            asm volatile("" : "+v"(pk0), "+v"(pk1));
-#endif
         };
 
         // TK 2: tile p-1's group of this lane is a candidate group of its column (its packed maximum x reaches the column's
@@ -547,32 +507,18 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 sm0 = *(const bf16x8*)(lb + wave * 2048 + lane * 16);
                 sm1 = *(const bf16x8*)(lb + wave * 2048 + 1024 + lane * 16);
             }
-#ifdef VOSPROP_STAMP
-            STAMP_AT(0);   // 0: step head (cursor offsets, accumulator zeroing) + whatever the previous step left
-#endif
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
-#ifdef VOSPROP_STAMP
-                if (ks == 8) STAMP_AT(1);   // 1: gaps 0-7
-#endif
                 if (MAT != 2) {
-#if VOSPROP_DABLATE & 16
-                    asm volatile("" : "+v"(fr.a[ks & 7]));
-#else
                     S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr.a[ks & 7], Bt[ks], S, 0, 0, 0);
-#endif
                     // refill the fragment slot just consumed: second half of this tile, then the first half of the next one
-#if !(VOSPROP_DABLATE & 2)
                     if (ks < 8) fr.a[ks] = *(const bf16x8*)(arow + (ks + 8) * 32);
                     else fr.a[ks - 8] = *(const bf16x8*)(nrow + (ks - 8) * 32);
-#endif
                 }
-#if !(VOSPROP_DABLATE & 4)
                 if (STAGER) {
                     if (kStageA) { if (ks % 3 == 1) stage_piece(b_st, ks / 3); }      // gaps 1, 4, 7, 10, 13: pieces 0..4
                     else if (ks == 2 || ks == 7 || ks == 12) stage_piece(b_st, ks / 5);
                 }
-#endif
                 if (MAT == 1) continue;                        // score tiles only
                 if (TK != 0) {
                     // ---- top-k passes: weighted exponents of tile p-1 and their group maximum (no exponential) ----
@@ -606,13 +552,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 // not left standing behind the 16th MFMA, in front of the label MFMAs that wait for them (hipcc otherwise bunches the
                 // last rows there: ~60 exposed cycles per step and wave).
                 auto soft_row = [&](int r) __attribute__((always_inline)) {
-#if VOSPROP_DABLATE & 1
-                    const float q = Sp[r];
-                    if (r == 15) { pk0 = Bt[0]; pk1 = Bt[1]; }
-                    if (false)
-#else
                     const float q = __builtin_amdgcn_exp2f(__builtin_fmaf(Sp[r], c, FUSED ? Wt[r] : -mc));
-#endif
                     if (PROB) {
                         if (r & 1) {
                             const bf16_t ha = (bf16_t)qprev, hb = (bf16_t)q;
@@ -652,14 +592,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                     if (STAGER) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
                     else asm volatile("s_barrier" ::: "memory");      // nothing of this wave's is in flight
                 }
-#ifndef VOSPROP_DENSE_NO_SGB
                 // pin the interleave (cdna guide T19): after each score MFMA its fragment refill and the 4-5 VALU instructions
                 // of one softmax row, in the MFMA's shadow - hipcc otherwise sinks the multiplies and packings below the chain
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
                 if (kRowsEarly && (ks == 12 || ks == 13)) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);   // two rows
                 else __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // <= 5 VALU (one of them the exponential)
-#endif
             }
             // the packed weights are "used" here, in the chain's basic block: hipcc otherwise sinks the multiplies and packings of the
             // fast path below the rescale branch, out of the MFMA shadow
@@ -673,16 +611,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 #pragma unroll
                 for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(Ek[i]));
             }
-#ifdef VOSPROP_STAMP
-            STAMP_AT(2);   // 2: gaps 8-15
-#endif
             if (STAGER) stage_advance();
             if (MAT != 1 && TK == 0) finish_prev(Sp, labp, lt0, lt1, pk0, pk1);
             bool tk_stored = false;      // TK 2: this wave issued the five dump stores in this step (they count in vmcnt)
             if (TK == 2) tk_stored = tk_dump(lt1);
-#ifdef VOSPROP_STAMP
-            STAMP_AT(3);   // 3: rescale check + label MFMAs
-#endif
             if (MAT == 2) {      // the scores of tile p as they came back from HBM (bf16: the materialised affinity's precision)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -712,7 +644,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                     if (acc_row(r, h) >= rows_last) S[r] = kNegBig;
             }
             // the prior tile of tile p (used from the next step on; tile p-1 is finished)
-            if (!PROB && need_w && !(VOSPROP_DABLATE & 64)) {
+            if (!PROB && need_w) {
                 asm volatile("; prior tile" ::: "memory");
                 prior_tile<FUSED>(lb, j, h, s_bx[sparse ? 1 : 0][tid], c,
                                   s_kq[sparse ? 1 : 0][tid] + (FUSED && TK == 0 ? st.m * c : 0.0f), Wt);      // (top-k: log2 w itself)
@@ -744,54 +676,36 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
                 // pieces of tile p+2: all but the 3 pieces and 2 stores issued in this step
                 asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             } else {
-#ifdef VOSPROP_STAMP
-                STAMP_AT(4);   // 4: tail mask, prior tile, cursor
-#endif
                 if (!MID_BARRIER) {
                     // TK 2: the five dump stores of this step were issued after its five pieces: they are the youngest
                     if (STAGER && kStageA && TK == 2 && tk_stored) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                     else if (STAGER && kStageA) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                     else if (STAGER) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-#ifdef VOSPROP_STAMP
-                    STAMP_AT(5);   // 5: wait for the own pieces of tile p+2
-#endif
-#if !(VOSPROP_DABLATE & 8)
                     __syncthreads();
-#endif
                 }
-#ifdef VOSPROP_STAMP
-                STAMP_AT(6);   // 6: barrier
-#endif
             }
             ring_advance();
         };
 
-        // ---- ONE barrier per step and wave, at a different place for the two waves of a SIMD (VOSPROP_DENSE_SKEW, default on):
+        // ---- ONE barrier per step and wave, at a different place for the two waves of a SIMD (MAT == 0):
         // waves 0-3 at the end of their step p, waves 4-7 after gap 7 of THEIR step p - so the second wave of every SIMD runs half
         // a step behind the first, and its serial tail (rescale check, label MFMAs, prior tile, cursor) sits under its partner's
-        // chain instead of under its partner's barrier wait (stamps, profiles/r02_dense_kernel_skew.txt).  With t in local steps:
+        // chain instead of under its partner's barrier wait (profiles/r02_dense_kernel_stamps.txt).  With t in local steps:
         // tile t is written at t-3+[.1,.8], read at [t-.5, t+1.6]; barrier k is passed at local time k+1 (first group) / k+.5
         // (second).  Visibility: every wave has waited for its pieces of tile k+2 before barrier k; the earliest read of tile t
         // (local t-.5) is after barrier t-2 (first group) or t-1 (second).  Re-use: the slot of tile t is re-targeted for tile t+6
         // at local t+3.1 or later, i.e. after barrier t+2, which every wave passes at local >= t+2.5 > t+1.6 (with FIVE slots the
         // first group's pieces would overtake the second group's label reads - hence six).
         constexpr bool kSkew = MAT == 0;
-        const bool grp_b = kSkew && wave >= kWaves / 2 && !A.no_skew;
+        const bool grp_b = kSkew && wave >= kWaves / 2;
         // step forms: bit 0 = barrier after gap 7, bit 1 = this wave does not stage
-        typedef std::integral_constant<int, 0> GrpA;                       // waves 0-3 (and everybody in the old scheme)
+        typedef std::integral_constant<int, 0> GrpA;                       // waves 0-3 (and every wave of the MAT forms)
         typedef std::integral_constant<int, kStageA ? 3 : 1> GrpB;         // waves 4-7, skewed
-        typedef std::integral_constant<int, kStageA ? 2 : 0> GrpBflat;     // waves 4-7 with VOSPROP_DENSE_SKEW=0
-        const bool second = wave >= kWaves / 2;
         int p = 0;
         if (grp_b) {
             for (; p + 1 < n_steps; p += 2) {
                 step(GrpB(), S0, S1);
                 step(GrpB(), S1, S0);
-            }
-        } else if (kStageA && second) {
-            for (; p + 1 < n_steps; p += 2) {
-                step(GrpBflat(), S0, S1);
-                step(GrpBflat(), S1, S0);
             }
         } else {
             for (; p + 1 < n_steps; p += 2) {
@@ -835,7 +749,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         };
         if (p < n_steps) {
             if (grp_b) step(GrpB(), S0, S1);
-            else if (kStageA && second) step(GrpBflat(), S0, S1);
             else step(GrpA(), S0, S1);
             if (MAT != 1) drain(S0);
         } else {
@@ -843,13 +756,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the look-ahead pieces before the ring is re-staged
         __syncthreads();
-#ifdef VOSPROP_STAMP
-        STAMP_AT(8);                // 8: last tile's softmax + the segment's closing barrier
-        t_seg = tprev;              // the partial's stores count towards the next segment's prologue
-        if (A.dbg && lane == 0)
-            for (int k = 0; k < VOSPROP_NSTAMP; ++k)
-                atomicAdd(&A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + k], tsum[k]);
-#endif
 
         if (MAT == 1) continue;
         if (TK == 2) {      // how many groups this lane dumped in this share (every lane writes: no memset between steps)
@@ -882,14 +788,6 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             if (cls < A.d) part[(size_t)(2 + cls) * kBT] = st.Y[r];
         }
     }
-#ifdef VOSPROP_STAMP
-    if (A.dbg && lane == 0) {
-        unsigned long long rt1;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
-        A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + 9] = rt0;
-        A.dbg[((size_t)blockIdx.x * kWaves + wave) * VOSPROP_NSTAMP + 11] = rt1;
-    }
-#endif
 }
 
 }  // namespace vosprop

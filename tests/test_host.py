@@ -401,17 +401,16 @@ def test_shm_frame_loader(tmp_path, vos):
 
 
 @pytest.mark.parametrize('TT,NT', [(26, 1809), (26, 201), (7, 57), (57, 4050), (1, 8), (1, 1), (33, 999), (64, 640)])
-@pytest.mark.parametrize('streamk', [0, 1])
-def test_work_plan_covers_every_unit_once(vos, TT, NT, streamk):
+def test_work_plan_covers_every_unit_once(vos, TT, NT):
     """The segment table the kernels walk (engine.hip build_segments, through the vosprop_debug_plan test hook): every
     (target tile, reference tile) unit exactly once, a workgroup only touches its own XCD's eighth of the reference stream,
     loads are balanced, and the lockstep map keeps the workgroups of an XCD on the same reference tiles."""
     L = vos._native.lib()
     L.vosprop_debug_plan.restype = ctypes.c_int
-    L.vosprop_debug_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
-    n = L.vosprop_debug_plan(TT, NT, streamk, None, 0)
+    L.vosprop_debug_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    n = L.vosprop_debug_plan(TT, NT, None, 0)
     buf = (ctypes.c_int * (4 * n))()
-    assert L.vosprop_debug_plan(TT, NT, streamk, buf, n) == n
+    assert L.vosprop_debug_plan(TT, NT, buf, n) == n
     rows = np.ctypeslib.as_array(buf).reshape(n, 4)
     cover = np.zeros((TT, NT), np.int32)
     load = collections.Counter()
@@ -419,7 +418,7 @@ def test_work_plan_covers_every_unit_once(vos, TT, NT, streamk):
         x = b % 8
         assert ns > 0 and x * NT // 8 <= r_lo and r_lo + ns <= (x + 1) * NT // 8
         cover[tt, r_lo:r_lo + ns] += 1
-        load[b] += ns + (0 if streamk else 9)       # the lockstep map prices a segment start at 9 tile steps (VOSPROP_SEGCOST; measured)
+        load[b] += ns + 9       # the lockstep map prices a segment start at 9 tile steps (VOSPROP_SEGCOST; measured)
     assert cover.min() == 1 and cover.max() == 1
     if TT * NT >= 8 * 32 * 8:
         per_xcd = collections.defaultdict(list)
@@ -427,7 +426,7 @@ def test_work_plan_covers_every_unit_once(vos, TT, NT, streamk):
             per_xcd[b % 8].append(v)
         for x, v in per_xcd.items():
             assert max(v) <= min(v) * 1.1 + 8, (x, sorted(v))
-    if not streamk and TT >= 32:
+    if TT >= 32:
         # first round of the lockstep map: the 32 workgroups of XCD 0 start at the same reference tile with the same length
         first = {}
         for b, tt, r_lo, ns in rows:
@@ -459,7 +458,7 @@ def test_no_compiler_generated_m0_reader_in_the_propagation_kernels(tmp_path):
         m = re.match(r'^(_ZN7vosprop\w+):', ln)
         if m:
             kernel = m.group(1)
-        if kernel and ('prop_dense_kernel' in kernel or 'prop_bf16_kernel' in kernel):
+        if kernel and ('prop_dense_kernel' in kernel or 'prop_mask_kernel' in kernel):
             code = ln.split(';')[0]
             if re.search(r'\bm0\b', code):
                 seen += 1
@@ -467,6 +466,33 @@ def test_no_compiler_generated_m0_reader_in_the_propagation_kernels(tmp_path):
                     bad.append((kernel[:60], code.strip()))
     assert seen > 0, 'no LDS-DMA piece found: the check is not looking at the right kernels'
     assert not bad, bad[:5]
+
+
+def test_mask_loop_is_generated_and_passes_its_hazard_check():
+    """csrc/prop_mask_loop.inc - the hand-ordered tile loop of prop_mask_kernel - is the output of tools/gen_mask_loop.py: the
+    generator derives every s_waitcnt lgkmcnt from a model of the LDS return queue and FAILS on any dependent pair closer than the
+    wait states the hardware does not interlock (MFMA result -> VALU / other MFMA, VALU -> MFMA operand, transcendental -> VALU,
+    M0 write -> LDS-DMA).  Regenerating must reproduce the committed file byte for byte (so the checks ran on what ships)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(ROOT / 'tools' / 'gen_mask_loop.py'), '--check'], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_mask_loop_hazard_checker_catches_a_short_distance():
+    """The checker is not vacuous: the same stream with the first softmax row pulled next to the chain's last MFMA must be refused."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('gen_mask_loop', ROOT / 'tools' / 'gen_mask_loop.py')
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    ins = [g.Ins('v_mfma_f32_32x32x16_bf16 v[128:143], v[192:195], v[64:67], v[128:143]', 'mfma',
+                 reads=set(range(192, 196)) | set(range(64, 68)) | set(range(128, 144)), writes=range(128, 144))]
+    ins += [g.Ins('s_nop 0', 'nop') for _ in range(3)]
+    ins += [g.Ins('v_exp_f32 v52, v128', 'trans', reads=[128], writes=[52])]
+    with pytest.raises(SystemExit):
+        g.check_hazards(ins, 0)
+    ins[1:4] = [g.Ins('s_nop 7', 'nop', nops=8), g.Ins('s_nop 3', 'nop', nops=4)]
+    g.check_hazards(ins, 0)
 
 
 def test_set_deterministic_switches_the_library_and_the_solver_family(monkeypatch):
