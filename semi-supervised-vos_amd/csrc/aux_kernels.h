@@ -77,11 +77,27 @@ __global__ __launch_bounds__(256) void push_hwc_kernel(const T* __restrict__ src
 // the A-operand order that matches an accumulator tile reused as the B operand (see prop_bf16.h).
 __device__ inline int lab_row(int s, int lane, int e) { return 16 * s + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3); }
 
+// The same labels as ONE v_mfma_f32_16x16x32_bf16 A fragment per tile (prop_mask16.h; one-hot labels of <= 16 classes): element j of
+// lane l is L[class = l & 15][row], row = 4 (l >> 4) + j for j < 4 and 16 + 4 (l >> 4) + (j - 4) above - the rows whose weights the
+// lane with k block l >> 4 holds in its two row-block accumulators.  [tile][64 lanes][8] bf16 = 1 KiB per tile.
+__device__ inline int lab16_row(int lane, int j) { return (j < 4 ? 0 : 12) + 4 * (lane >> 4) + j; }
+
 // One-hot labels from a class-index map (reference index_to_onehot, src/utils/utils.py:59-68).
 // One thread per 16-byte chunk: grid*block >= tiles*128.
-__global__ void pack_cls_kernel(const uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi, int HW, int tiles) {
+__global__ void pack_cls_kernel(const uint8_t* __restrict__ cls, bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab16, int HW,
+                                int tiles) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= tiles * 128) return;
+    if (lab16 && gid < tiles * 64) {
+        const int tile16 = gid >> 6, lane16 = gid & 63;
+        bf16x8 o16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int p = tile16 * kTileR + lab16_row(lane16, e);
+            o16[e] = (bf16_t)((p < HW && cls[p] == (lane16 & 15)) ? 1.0f : 0.0f);
+        }
+        *(bf16x8*)(lab16 + (size_t)gid * 8) = o16;
+    }
     const int tile = gid >> 7, s = (gid >> 6) & 1, lane = gid & 63;
     const int k = lane & 31;
     bf16x8 o;
@@ -124,7 +140,7 @@ __global__ void pack_f32_kernel(const float* __restrict__ L, size_t ld, int d, b
 }
 
 __device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t* clsv, int d, int HW, int prob,
-                                         bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo);
+                                         bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, bf16_t* __restrict__ lab16 = nullptr);
 
 // Merge the partials of target pixels, normalise, arg-max, and write the new frame's labels in MFMA operand order.
 //   out[k,t] = sum_u Y_u[k] 2^((m_u - M) c) / sum_u l_u 2^((m_u - M) c)      (reference predict.py:55-70)
@@ -151,7 +167,8 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
                                                       float* __restrict__ pred, uint8_t* __restrict__ cls,
                                                       bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, int prob,
                                                       const UpArgs up, const uint4* __restrict__ cp_src,
-                                                      uint4* __restrict__ cp_dst, int cp_n, int no_l, int cp_f16) {
+                                                      uint4* __restrict__ cp_dst, int cp_n, int no_l, int cp_f16,
+                                                      bf16_t* __restrict__ lab16) {
     __shared__ float red[4][kMaxClasses + 2][64];
     __shared__ float outv[kMaxClasses][64];
     __shared__ uint8_t clsv[64];
@@ -269,13 +286,23 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
         }
     }
     if (!lab_hi) return;
-    pack_block_labels(outv, clsv, d, HW, prob, lab_hi, lab_lo);
+    pack_block_labels(outv, clsv, d, HW, prob, lab_hi, lab_lo, lab16);
 }
 
 // Label tiles of one 64-pixel block in MFMA A-operand order, from LDS copies of the block's results (256 threads).
 __device__ inline void pack_block_labels(const float (*outv)[64], const uint8_t* clsv, int d, int HW, int prob,
-                                         bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo) {
+                                         bf16_t* __restrict__ lab_hi, bf16_t* __restrict__ lab_lo, bf16_t* __restrict__ lab16) {
     const int tid = threadIdx.x;
+    if (lab16 && !prob && tid < 128) {      // the two tiles of this 64-pixel block in the 16x16x32 fragment order (lab16_row)
+        const int tl16 = tid >> 6, lane16 = tid & 63;
+        bf16x8 o16;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pc = tl16 * 32 + lab16_row(lane16, e);
+            o16[e] = (bf16_t)((blockIdx.x * 64 + pc < HW && clsv[pc] == (lane16 & 15)) ? 1.0f : 0.0f);
+        }
+        *(bf16x8*)(lab16 + ((size_t)(blockIdx.x * 2 + tl16) * 64 + lane16) * 8) = o16;
+    }
     const int tl = tid >> 7, s = (tid >> 6) & 1, lane = tid & 63, k = lane & 31;
     const int tile = blockIdx.x * 2 + tl;
     bf16x8 oh, ol;

@@ -19,6 +19,7 @@
 #include "prop_bf16.h"
 #include "prop_dense.h"
 #include "prop_mask.h"
+#include "prop_mask16.h"
 #include "prop_f32.h"
 #include "pointwise.h"
 #include "encoder_ops.h"
@@ -32,6 +33,7 @@ struct Ring {
     float* featf = nullptr;    // [cap][HWp][kC] f32      (VOSPROP_PREC_F32: the features are never rounded)
     bf16_t* lab_hi = nullptr;  // [cap][tiles][2][64][8]
     bf16_t* lab_lo = nullptr;
+    bf16_t* lab16 = nullptr;   // [cap][tiles][64][8]: the 16x16x32 label fragment (one-hot, <= 16 classes; prop_mask16.h)
     uint8_t* cls = nullptr;    // [cap][HWp]
     int cap = 0;
 };
@@ -151,6 +153,8 @@ int ring_alloc(vosprop_ctx* ctx, Ring& r, int cap) {
     else r.feat = (bf16_t*)fp;
     HIP_TRY(ctx, hipMalloc((void**)&r.lab_hi, lab_b));
     HIP_TRY(ctx, hipMalloc((void**)&r.lab_lo, lab_b));
+    HIP_TRY(ctx, hipMalloc((void**)&r.lab16, lab_b / 2));
+    HIP_TRY(ctx, hipMemset(r.lab16, 0, lab_b / 2));
     HIP_TRY(ctx, hipMalloc((void**)&r.cls, cls_b));
     HIP_TRY(ctx, hipMemset(fp, 0, feat_b));
     HIP_TRY(ctx, hipMemset(r.lab_hi, 0, lab_b));
@@ -165,6 +169,7 @@ void ring_free(Ring& r) {
     if (r.featf) (void)hipFree(r.featf);
     if (r.lab_hi) (void)hipFree(r.lab_hi);
     if (r.lab_lo) (void)hipFree(r.lab_lo);
+    if (r.lab16) (void)hipFree(r.lab16);
     if (r.cls) (void)hipFree(r.cls);
     r = Ring();
 }
@@ -457,8 +462,12 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
         else hipLaunchKernelGGL((prop_dense_kernel<true, false>), grid, block, 0, s, a);
     } else {
         if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<false, true>), grid, block, 0, s, a);
-        else if (lp.no_l) {      // the mask-only form (prop_mask.h)
-            if (e0) hipExtLaunchKernelGGL(prop_mask_kernel, grid, block, 0, s, e0, e1, 0, a);
+        else if (lp.no_l) {      // the mask-only form: prop_mask16.h (16x16x32 MFMAs, <= 16 classes) or prop_mask.h
+            static const int m16_env = getenv("VOSPROP_MASK16") ? atoi(getenv("VOSPROP_MASK16")) : 1;
+            if (m16_env && a.d <= kM16MaxClasses) {
+                if (e0) hipExtLaunchKernelGGL(prop_mask16_kernel, grid, block, 0, s, e0, e1, 0, a);
+                else hipLaunchKernelGGL(prop_mask16_kernel, grid, block, 0, s, a);
+            } else if (e0) hipExtLaunchKernelGGL(prop_mask_kernel, grid, block, 0, s, e0, e1, 0, a);
             else hipLaunchKernelGGL(prop_mask_kernel, grid, block, 0, s, a);
         } else if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, a);
@@ -502,7 +511,7 @@ int ensure_buf(vosprop_ctx* ctx, T** p, size_t* have, size_t bytes, hipStream_t 
 // One propagation: sampled frames `idx` (history indices, ring slot = idx % cap) against the target slot.
 int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int frame_idx, int target_slot, int d,
               bool prob, bool lab_lo, float sigma1, float sigma2, float temperature, float* pred, uint8_t* cls,
-              bf16_t* new_lab_hi, bf16_t* new_lab_lo, hipStream_t s) {
+              bf16_t* new_lab_hi, bf16_t* new_lab_lo, hipStream_t s, bf16_t* new_lab16 = nullptr) {
     const int topk = ctx->cfg.topk;
     if (n_ref < 1 || n_ref > kMaxRef) return fail(ctx, VOSPROP_E_INVALID, "n_ref out of range");
     if (d < 1 || d > kMaxClasses) return fail(ctx, VOSPROP_E_UNSUPPORTED, "d > VOSPROP_MAX_CLASSES");
@@ -521,6 +530,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.coord_tab = ctx->coord_tab;
     a.lab_hi = ring.lab_hi;
     a.lab_lo = lab_lo ? ring.lab_lo : nullptr;
+    a.lab16 = ring.lab16;
     for (int n = 0; n < n_ref; ++n) a.slot[n] = slots[n];
     a.sparse_mask = 0;
     if (!prob && frame_idx > 15)   // reference src/model/predict.py:59-64
@@ -684,7 +694,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         const int cp_n = ctx->fuse_push ? (int)((size_t)ctx->HW * kC * sizeof(bf16_t) / 16) : 0;
         hipLaunchKernelGGL(combine_kernel, cgrid, dim3(256), 0, s, ctx->part, plan->d_off, plan->d_list, d, ctx->HW, a.c, pred,
                            cls, new_lab_hi, new_lab_lo, prob ? 1 : 0, up, (const uint4*)ctx->fuse_push, (uint4*)target_in_ring, cp_n,
-                           lp.no_l ? 1 : 0, ctx->fuse_push && ctx->fuse_f16 ? 1 : 0);
+                           lp.no_l ? 1 : 0, ctx->fuse_push && ctx->fuse_f16 ? 1 : 0, new_lab16);
         // re-runs of this propagation (vosprop_time_last_propagation, debug hooks) read the target from the ring: the caller's
         // buffer is only promised until the work enqueued by this call has run
         a.target_feat = target_in_ring;
@@ -710,9 +720,9 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     return VOSPROP_OK;
 }
 
-int pack_labels_from_cls(vosprop_ctx* ctx, const uint8_t* cls, bf16_t* lab_hi, hipStream_t s) {
+int pack_labels_from_cls(vosprop_ctx* ctx, const uint8_t* cls, bf16_t* lab_hi, bf16_t* lab16, hipStream_t s) {
     const int n = ctx->tiles * 128;
-    hipLaunchKernelGGL(pack_cls_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cls, lab_hi, ctx->HW, ctx->tiles);
+    hipLaunchKernelGGL(pack_cls_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cls, lab_hi, lab16, ctx->HW, ctx->tiles);
     HIP_TRY(ctx, hipGetLastError());
     return VOSPROP_OK;
 }
@@ -1005,7 +1015,7 @@ static int begin_with_lowres(vosprop_ctx* ctx, const std::vector<uint8_t>& cls, 
     if (ctx->stage_busy) HIP_TRY(ctx, hipEventSynchronize(ctx->stage_ev));
     memcpy(ctx->stage_host, cls.data(), cls.size());
     HIP_TRY(ctx, hipMemcpyAsync(ctx->ring.cls, ctx->stage_host, cls.size(), hipMemcpyHostToDevice, s));
-    int rc = pack_labels_from_cls(ctx, ctx->ring.cls, ctx->ring.lab_hi, s);
+    int rc = pack_labels_from_cls(ctx, ctx->ring.cls, ctx->ring.lab_hi, ctx->ring.lab16, s);
     if (rc) return rc;
     const size_t lab_slot_b = (size_t)ctx->tiles * 2 * 64 * 8 * sizeof(bf16_t);
     HIP_TRY(ctx, hipMemsetAsync(ctx->ring.lab_lo, 0, lab_slot_b, s));
@@ -1126,7 +1136,8 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     ctx->fuse_f16 = fuse_push && feat_dtype == (VOSPROP_DT_F16 | VOSPROP_LAYOUT_HWC);
     ctx->mask_only = pred_out_dev == nullptr;
     rc = propagate(ctx, R, slots, n_ref, f, slot, ctx->d, prob, prob, ctx->cfg.sigma1, ctx->cfg.sigma2,
-                   ctx->cfg.temperature, ctx->pred_buf, cls_slot, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s);
+                   ctx->cfg.temperature, ctx->pred_buf, cls_slot, R.lab_hi + slot * lab_slot, R.lab_lo + slot * lab_slot, s,
+                   R.lab16 + slot * (lab_slot / 2));
     ctx->fuse_mask = nullptr;
     ctx->fuse_push = nullptr;
     ctx->mask_only = false;

@@ -1,0 +1,357 @@
+// prop_mask_kernel on v_mfma_f32_16x16x32_bf16 (development twin of prop_mask.h; see tools/gen_mask16_loop.py for the step and for
+// why this MFMA shape: the chip is power-bound under this kernel and the 16x16x32 shape moves half the accumulator bytes per MAC).
+//
+// Layouts (MFMA 16x16x32: A[row l&15][k = 8 (l>>4) + j], B[k = 8 (l>>4) + j][col l&15], D col = l&15, row = 4 (l>>4) + reg):
+//   * a wave owns 32 target columns = two column blocks cb of 16; a lane holds columns 16 cb + (l & 15), cb = 0, 1, and k block
+//     kb = l >> 4; target fragments B[cb][ks] = channels 32 ks + 8 kb .. + 7 of its column (64 registers, pre-multiplied by c);
+//   * a reference tile = 32 rows = two row blocks rb; A(rb, ks) = one ds_read_b128 at row (16 rb + (l & 15)), channels
+//     32 ks + 8 kb, from 544-B padded LDS rows (16-B slot = (2 row + kb) mod 16: conflict-free in every 16-lane group);
+//   * S[rb][cb] = 4 registers: rows 16 rb + 4 kb + i of column 16 cb + (l & 15); the lane's 8 values of a column are rows
+//     {4 kb + i} and {16 + 4 kb + i}: packed to bf16 they ARE the B operand (k = 8 kb + j) of the label MFMA
+//     Y[cb] (16 classes x 16 columns) += L (16 classes x 32 rows) pk[cb], with the label fragment stored in that row order
+//     (lab16 ring, aux_kernels.h lab16_row) - ONE 16-cycle MFMA per column block instead of two 32-cycle ones, d <= 16;
+//   * the prior tile LM[rb][cb] = coordinates(rb) x target-side constants[cb]: K = 32 with channels 16..31 zero on the target side
+//     (k blocks 2, 3), so whatever finite bytes those lanes read on the reference side do not matter.
+#pragma once
+#include "common.h"
+#include "prop_bf16.h"
+#include "prop_mask.h"      // cvt_pk_bf16, vector typedefs, table constants
+#ifndef VOSPROP_MASK16_LOOP_INC
+#define VOSPROP_MASK16_LOOP_INC "prop_mask16_loop.inc"
+#endif
+// the two generated files define the same macro names: take this kernel's set
+#undef VOSPROP_MASK_SLOT
+#undef VOSPROP_MASK_NSLOT
+#undef VOSPROP_MASK_OFF_COORD
+#undef VOSPROP_MASK_OFF_LAB
+#undef VOSPROP_MASK_ALARM
+#undef VOSPROP_MASK_REG_AUX
+#undef VOSPROP_MASK_REG_CTL
+#undef VOSPROP_MASK_REG_CB
+#undef VOSPROP_MASK_REG_B0
+#undef VOSPROP_MASK_REG_B1
+#undef VOSPROP_MASK_REG_B2
+#undef VOSPROP_MASK_REG_B3
+#undef VOSPROP_MASK_REG_S0
+#undef VOSPROP_MASK_REG_S1
+#undef VOSPROP_MASK_REG_Y
+#undef VOSPROP_MASK_REG_PK
+#undef VOSPROP_MASK_REG_LAB
+#undef VOSPROP_MASK_CTL_SRCA
+#undef VOSPROP_MASK_CTL_SRCB
+#undef VOSPROP_MASK_CTL_SRC3
+#undef VOSPROP_MASK_CTL_ROWLO
+#undef VOSPROP_MASK_CTL_ROWHI
+#undef VOSPROP_MASK_CTL_LANELO
+#undef VOSPROP_MASK_CTL_LANEHI
+#undef VOSPROP_MASK_CTL_TA
+#undef VOSPROP_MASK_CTL_TB
+#undef VOSPROP_MASK_CTL_MX
+#undef VOSPROP_MASK_CTL_TABA
+#undef VOSPROP_MASK_CTL_TABB
+#undef VOSPROP_MASK_AUX_KQ1
+#undef VOSPROP_MASK_AUX_KQ2
+#undef VOSPROP_MASK_AUX_MC
+#undef VOSPROP_MASK_TAB_ENTRY
+#undef VOSPROP_MASK_TAB_BLOCK
+#undef VOSPROP_MASK_AHEAD
+#undef VOSPROP_MASK_CLOBBERS
+#undef VOSPROP_MASK_LOOP
+#include VOSPROP_MASK16_LOOP_INC
+
+namespace vosprop {
+
+constexpr int kM16Slot = VOSPROP_MASK_SLOT;
+constexpr int kM16Ring = VOSPROP_MASK_NSLOT;
+constexpr int kM16OffCoord = VOSPROP_MASK_OFF_COORD;
+constexpr int kM16OffLab = VOSPROP_MASK_OFF_LAB;
+constexpr int kM16RowB = VOSPROP_MASK_ROWB;
+constexpr float kM16Alarm = VOSPROP_MASK_ALARM;
+constexpr int kM16Ahead = VOSPROP_MASK_AHEAD;
+constexpr int kM16TabBlock = VOSPROP_MASK_TAB_BLOCK;
+constexpr int kM16TabEntry = VOSPROP_MASK_TAB_ENTRY;
+constexpr int kM16Lab = 1024;                               // bytes of one tile's label fragment (16 classes x 32 rows bf16)
+constexpr int kM16MaxClasses = 16;
+static_assert(kM16OffCoord == kTileR * kM16RowB && kM16OffLab == kM16OffCoord + kLdsCoord && kM16Slot == kM16OffLab + kM16Lab, "slot layout");
+
+__global__ __launch_bounds__(kWaves * 64, 2) void prop_mask16_kernel(const PropArgs A) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kM16Ring * kM16Slot];
+    __shared__ unsigned s_off[2 * kMaxRef];      // per sampled frame: byte offset of its slot in the feature ring / lab16 ring
+    __shared__ __attribute__((aligned(16))) unsigned s_tab[kMaskTabCap * (kM16TabEntry / 4)];      // control table (prop_mask.h)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int TPF = A.tiles_per_frame;
+    const int N = A.n_ref;
+    const float c = A.c;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const unsigned smem_base = (unsigned)(size_t)(lds_ptr)smem;
+
+    if (tid < kMaxRef) {
+        const unsigned sl = (unsigned)A.slot[tid < N ? tid : 0];
+        s_off[tid] = sl * (unsigned)((size_t)A.HWp * (kC * 2));
+        s_off[kMaxRef + tid] = sl * (unsigned)(TPF * kM16Lab);
+    }
+
+    // ---- staging roles: every wave stages feature pieces w and w + 8 of the padded 544-B row image (17 KiB = 17 pieces, all of
+    // them full); waves 0-3 (role A) a third piece each - feature piece 16, the coordinates, the label fragment (waves 2 AND 3: the
+    // same bytes to the same place; the role-A stream has three pieces)
+    auto feat_src_off = [&](int piece) -> unsigned {
+        const int qq = 64 * piece + lane;
+        const int row = qq / 34;
+        int ch = qq - row * 34;
+        if (ch >= 32) ch = 31;      // the two pad chunks of a row: any valid source
+        return (unsigned)(row * 512 + ch * 16);
+    };
+    const bool role_a = wave < kWaves / 2;
+    const unsigned role_b = ((unsigned)wave >> 2) & 1u;      // (kWaves == 8)
+    const unsigned src_a = feat_src_off(wave), src_b = feat_src_off(wave + 8);
+    const unsigned char* const feat_base = (const unsigned char*)A.feat_ring;
+    const unsigned char* third_base = feat_base;
+    unsigned src_3 = (unsigned)lane * 16, lds3_off = 16 * 1024;
+    int third_col = 0;      // which offset the third piece follows: 0 feature tile, 1 coordinate tile, 2 label tile
+    if (wave == 0) {
+        src_3 = feat_src_off(16);
+    } else if (wave == 1) {
+        third_base = (const unsigned char*)A.coord_tab;
+        lds3_off = kM16OffCoord;
+        third_col = 1;
+    } else if (wave == 2 || wave == 3) {
+        third_base = (const unsigned char*)A.lab16;
+        lds3_off = kM16OffLab;
+        third_col = 2;
+    }
+    third_col = __builtin_amdgcn_readfirstlane(third_col);
+    lds3_off = (unsigned)__builtin_amdgcn_readfirstlane((int)lds3_off);
+    const unsigned fb_lo = (unsigned)(size_t)feat_base, fb_hi = (unsigned)((size_t)feat_base >> 32);
+    const unsigned tb_lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)third_base);
+    const unsigned tb_hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)third_base >> 32));
+    const unsigned ldsa = smem_base + (unsigned)wave * 1024;
+    const unsigned lds3 = __builtin_amdgcn_readfirstlane(smem_base + lds3_off);
+    const unsigned tab_base = (unsigned)(size_t)(lds_ptr)s_tab;
+    const unsigned tab_col = third_col == 0 ? 12u : third_col == 1 ? 4u : 8u;      // this wave's TB column inside an entry
+
+    const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
+    __syncthreads();      // s_off
+    for (int si = seg0; si < seg1; ++si) {
+        const Segment sg = A.segs[si];
+        const int tt = __builtin_amdgcn_readfirstlane(sg.tt);
+        const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);
+        const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
+        const int part_slot = __builtin_amdgcn_readfirstlane(sg.slot);
+
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+        const int lane_l = tid_l & 63, j16 = tid_l & 15, kb = (tid_l >> 4) & 3;
+
+        // ---- target (B operand) fragments [cb][ks]: loads fly under the rest of the prologue
+        int tcol[2];
+        u32x4 Braw[16];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            tcol[cb] = tt * kBT + wave * kColsPerWave + 16 * cb + j16;
+            const int t_ld = tcol[cb] < A.target_rows ? tcol[cb] : A.target_rows - 1;
+            const bf16_t* trow = A.target_feat + (size_t)t_ld * kC + kb * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) Braw[cb * 8 + ks] = *(const u32x4*)(trow + ks * 32);
+        }
+        // target-side constants of the prior MFMA [sigma][cb]: k blocks 0 / 1 hold K channels 0-7 / 8-15 (engine.hip
+        // build_target_consts), k blocks 2 / 3 are zero; g Q_t c per (sigma, column)
+        u32x4 cbv[2][2];
+        float kq[2][2];
+#pragma unroll
+        for (int sgm = 0; sgm < 2; ++sgm)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int tq = tcol[cb] < A.HW ? tcol[cb] : A.HW - 1;
+                const u32x4 v = ((const u32x4*)A.tc_b)[((size_t)sgm * A.HWp + tq) * 2 + (kb & 1)];
+                cbv[sgm][cb] = kb < 2 ? v : u32x4{0u, 0u, 0u, 0u};
+                kq[sgm][cb] = A.tc_kq[(size_t)sgm * A.HWp + tq];
+            }
+
+        // ---- control table of the segment -> LDS (prop_mask.h has the entry format)
+        for (int p0 = tid_l; p0 < n_steps + kM16TabBlock + kM16Ahead; p0 += kWaves * 64) {
+            const int p = p0 < n_steps - 1 ? p0 : n_steps - 1;
+            const int r = r_lo + p;
+            const int tile = r / N, n = r - tile * N;
+            const unsigned fo = s_off[n] + (unsigned)tile * (unsigned)kGlbFeat;
+            int p2 = p0 - (kM16Ahead - 1);
+            if (p2 > n_steps - 1) p2 = n_steps - 1;
+            unsigned flags = 0;
+            if (p2 >= 1) {
+                const int r2 = r_lo + p2;
+                const int tile2 = r2 / N, n2 = r2 - tile2 * N;
+                const unsigned sp = (unsigned)(A.sparse_mask >> n2) & 1u;
+                const unsigned sp_prev = n2 > 0 ? (unsigned)(A.sparse_mask >> (n2 - 1)) & 1u : 0u;
+                flags = ((n2 == 0 || sp != sp_prev) ? 1u : 0u) | (sp << 1);
+            }
+            *(u32x4*)(s_tab + p0 * (kM16TabEntry / 4)) =
+                u32x4{fo | flags, (unsigned)tile * (unsigned)kLdsCoord, s_off[kMaxRef + n] + (unsigned)tile * (unsigned)kM16Lab, fo};
+        }
+        __syncthreads();
+        const unsigned tab_a = s_tab[lane_l * (kM16TabEntry / 4)];
+        const unsigned tab_b = s_tab[lane_l * (kM16TabEntry / 4) + tab_col / 4];
+
+        // "tile -1" takes its labels from the last slot: zero them (0 x NaN)
+        if (tid_l < kM16Lab / 16) *(f32x4*)(smem + (kM16Ring - 1) * kM16Slot + kM16OffLab + tid_l * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- tiles 0 .. kM16Ahead-1 -> slots 0 .. kM16Ahead-1
+#pragma unroll
+        for (int i = 0; i < kM16Ahead; ++i) {
+            const unsigned ea = (unsigned)__builtin_amdgcn_readlane((int)tab_a, i) & ~15u;
+            const unsigned eb = (unsigned)__builtin_amdgcn_readlane((int)tab_b, i);
+            const unsigned lds = smem_base + (unsigned)i * kM16Slot;
+            glds16s2(src_a, ea, feat_base, lds, (unsigned)wave * 1024);
+            glds16s2(src_b, ea, feat_base, lds, ((unsigned)wave + 8) * 1024);
+            if (role_a) glds16s2(src_3, eb, third_base, lds, lds3_off);
+        }
+
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(Braw[i]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // c folded into the target side: T' = bf16(c T) (f16 features are converted on the way, one rounding); Bq = [cb][ks] x 4
+        u32x16 Bq0, Bq1, Bq2, Bq3;
+#define VOSPROP_M16_SET(idx, val)                          \
+    do {                                                   \
+        if ((idx) < 16) Bq0[(idx) & 15] = (val);           \
+        else if ((idx) < 32) Bq1[(idx) & 15] = (val);      \
+        else if ((idx) < 48) Bq2[(idx) & 15] = (val);      \
+        else Bq3[(idx) & 15] = (val);                      \
+    } while (0)
+        if (A.target_f16) {
+#pragma unroll
+            for (int f = 0; f < 16; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned w = Braw[f][i];
+                    const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu));
+                    const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+                    VOSPROP_M16_SET(f * 4 + i, cvt_pk_bf16(lo * c, hi * c));
+                }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 16; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned w = Braw[f][i];
+                    VOSPROP_M16_SET(f * 4 + i, cvt_pk_bf16(__uint_as_float(w << 16) * c, __uint_as_float(w & 0xFFFF0000u) * c));
+                }
+        }
+#undef VOSPROP_M16_SET
+        __syncthreads();      // the first tiles and the zeroed label area are visible
+
+        // ---- inputs of the loop statement ----
+        u32x16 CTL, CB;
+        f32x8 AUX;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) CTL[r] = 0u;
+#pragma unroll
+        for (int sgm = 0; sgm < 2; ++sgm)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) CB[8 * sgm + 4 * cb + i] = cbv[sgm][cb][i];
+        const unsigned row_lo = smem_base + (unsigned)(j16 * kM16RowB + kb * 16);
+        const unsigned coord_lo = smem_base + (unsigned)((kb & 1) * 512 + j16 * 16);
+        CTL[VOSPROP_MASK_CTL_SRCA] = src_a;
+        CTL[VOSPROP_MASK_CTL_SRCB] = src_b;
+        CTL[VOSPROP_MASK_CTL_SRC3] = src_3;
+        CTL[VOSPROP_MASK_CTL_ROWLO] = row_lo;
+        CTL[VOSPROP_MASK_CTL_ROWHI] = row_lo + 3u * kM16Slot;
+        CTL[VOSPROP_MASK_CTL_LANELO] = smem_base + (unsigned)lane_l * 16;
+        CTL[VOSPROP_MASK_CTL_LANEHI] = smem_base + (unsigned)lane_l * 16 + 3u * kM16Slot;
+        CTL[VOSPROP_MASK_CTL_COORDLO] = coord_lo;
+        CTL[VOSPROP_MASK_CTL_COORDHI] = coord_lo + 3u * kM16Slot;
+        CTL[VOSPROP_MASK_CTL_TA] = tab_a;
+        CTL[VOSPROP_MASK_CTL_TB] = tab_b;
+        CTL[VOSPROP_MASK_CTL_TABA] = (unsigned)lane_l * kM16TabEntry;
+        CTL[VOSPROP_MASK_CTL_TABB] = (unsigned)lane_l * kM16TabEntry + tab_col;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) AUX[r] = 0.0f;
+#pragma unroll
+        for (int sgm = 0; sgm < 2; ++sgm)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) AUX[VOSPROP_MASK_AUX_KQ + 2 * sgm + cb] = kq[sgm][cb];
+        const int n0 = r_lo - (r_lo / N) * N;
+        const unsigned sp0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((A.sparse_mask >> n0) & 1ull));
+
+        // ---- the tile loop, its control and its rare paths: ONE statement per segment ----
+        f32x16 S0, S1;
+        f32x8 Y;
+        u32x16 PK;
+        u32x4 LAB;
+        {
+            const unsigned un = (unsigned)n_steps;
+            asm volatile(VOSPROP_MASK_LOOP
+                         : "=" VOSPROP_MASK_REG_S0(S0), "=" VOSPROP_MASK_REG_S1(S1), "=" VOSPROP_MASK_REG_Y(Y),
+                           "=" VOSPROP_MASK_REG_PK(PK), "=" VOSPROP_MASK_REG_LAB(LAB), "+" VOSPROP_MASK_REG_AUX(AUX),
+                           "+" VOSPROP_MASK_REG_CB(CB), "+" VOSPROP_MASK_REG_CTL(CTL)
+                         : VOSPROP_MASK_REG_B0(Bq0), VOSPROP_MASK_REG_B1(Bq1), VOSPROP_MASK_REG_B2(Bq2), VOSPROP_MASK_REG_B3(Bq3),
+                           [n] "s"(un), [fb_lo] "s"(fb_lo), [fb_hi] "s"(fb_hi), [tb_lo] "s"(tb_lo), [tb_hi] "s"(tb_hi),
+                           [ldsa] "s"(ldsa), [lds3] "s"(lds3), [role] "s"(role_b), [tab] "s"(tab_base), [sp0] "s"(sp0)
+                         : VOSPROP_MASK_CLOBBERS);
+        }
+        const bool centred = n_steps >= 2;      // the first tile went through the rescale path (boundary 2)
+
+        // ---- the segment's last two tiles have no chain to hide under ----
+        f32x4 Yc[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) Yc[cb] = f32x4{Y[4 * cb], Y[4 * cb + 1], Y[4 * cb + 2], Y[4 * cb + 3]};
+        const bf16x8 labp = __builtin_bit_cast(bf16x8, LAB);
+        const bool odd = n_steps & 1;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {      // tile n-2: pk and its label fragment are in registers (a one-step segment finds zeros)
+            const int o = 4 * cb;
+            const u32x4 p = odd ? u32x4{PK[8 + o], PK[9 + o], PK[10 + o], PK[11 + o]} : u32x4{PK[o], PK[o + 1], PK[o + 2], PK[o + 3]};
+            Yc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(labp, __builtin_bit_cast(bf16x8, p), Yc[cb], 0, 0, 0);
+        }
+        float Mc[2];
+        {   // tile n-1: weights from its scores, labels from its ring slot
+            const int slot = (n_steps - 1) % kM16Ring;
+            const bf16x8 lab1 = *(const bf16x8*)(smem + slot * kM16Slot + kM16OffLab + lane_l * 16);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                float sv[8];      // rows 4 kb + i, then 16 + 4 kb + i, of column 16 cb + j16
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sv[4 * rb + i] = odd ? S0[8 * rb + 4 * cb + i] : S1[8 * rb + 4 * cb + i];
+                float xm = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+                xm = fmaxf(xm, __shfl_xor(xm, 16));
+                xm = fmaxf(xm, __shfl_xor(xm, 32));
+                const bool forced = !centred;
+                const bool mine = forced || xm > kM16Alarm;
+                const float shift = mine ? xm : 0.0f;
+                const float sc = forced ? 1.0f : __builtin_amdgcn_exp2f(-shift);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Yc[cb][i] *= sc;
+                Mc[cb] = AUX[VOSPROP_MASK_AUX_MC + cb] + shift;
+                u32x4 p;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    p[i] = cvt_pk_bf16(__builtin_amdgcn_exp2f(sv[2 * i] - shift), __builtin_amdgcn_exp2f(sv[2 * i + 1] - shift));
+                Yc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lab1, __builtin_bit_cast(bf16x8, p), Yc[cb], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the look-ahead pieces before the ring is re-staged
+        __syncthreads();
+
+        // ---- this segment's partial: rows (m, l = 0, numerators[d]) x 256 columns (combine_kernel, no_l form) ----
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + 16 * cb + j16;
+            if (kb == 0) {
+                part[0] = Mc[cb] / c;
+                part[kBT] = 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cls = 4 * kb + i;
+                if (cls < A.d) part[(size_t)(2 + cls) * kBT] = Yc[cb][i];
+            }
+        }
+    }
+}
+
+}  // namespace vosprop
