@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void push_hwc_kernel(const T* __restrict__ src
 // the A-operand order that matches an accumulator tile reused as the B operand (see prop_bf16.h).
 __device__ inline int lab_row(int s, int lane, int e) { return 16 * s + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3); }
 
-// The same labels as ONE v_mfma_f32_16x16x32_bf16 A fragment per tile (prop_mask16.h; one-hot labels of <= 16 classes): element j of
+// The same labels as ONE v_mfma_f32_16x16x32_bf16 A fragment per tile (prop_mask.h; one-hot labels of <= 16 classes): element j of
 // lane l is L[class = l & 15][row], row = 4 (l >> 4) + j for j < 4 and 16 + 4 (l >> 4) + (j - 4) above - the rows whose weights the
 // lane with k block l >> 4 holds in its two row-block accumulators.  [tile][64 lanes][8] bf16 = 1 KiB per tile.
 __device__ inline int lab16_row(int lane, int j) { return (j < 4 ? 0 : 12) + 4 * (lane >> 4) + j; }

@@ -74,7 +74,7 @@ struct PropArgs {
     const bf16_t* coord_tab;    // [HWp/32][2][32][8]    reference-side spatial channels
     const bf16_t* lab_hi;       // [cap][HWp/32][2][64][8] labels in MFMA A-operand order (hi part)
     const bf16_t* lab_lo;       // same, low part (probability mode) or nullptr
-    const bf16_t* lab16;        // [cap][HWp/32][64][8] one-hot labels of <= 16 classes as ONE 16x16x32 MFMA A fragment per tile (prop_mask16.h)
+    const bf16_t* lab16;        // [cap][HWp/32][64][8] one-hot labels of <= 16 classes as ONE 16x16x32 MFMA A fragment per tile (prop_mask.h)
     bf16_t* smat;               // materialised-affinity variant only: [N * tiles][column blocks][64][16] bf16 score tiles
     float* part;                // [n_segments][part_rows][kBT]  per-segment partial (m, l, numerators)
     int slot[kMaxRef];          // ring slot of each sampled reference frame

@@ -19,7 +19,6 @@
 #include "prop_bf16.h"
 #include "prop_dense.h"
 #include "prop_mask.h"
-#include "prop_mask16.h"
 #include "prop_f32.h"
 #include "pointwise.h"
 #include "encoder_ops.h"
@@ -33,7 +32,7 @@ struct Ring {
     float* featf = nullptr;    // [cap][HWp][kC] f32      (VOSPROP_PREC_F32: the features are never rounded)
     bf16_t* lab_hi = nullptr;  // [cap][tiles][2][64][8]
     bf16_t* lab_lo = nullptr;
-    bf16_t* lab16 = nullptr;   // [cap][tiles][64][8]: the 16x16x32 label fragment (one-hot, <= 16 classes; prop_mask16.h)
+    bf16_t* lab16 = nullptr;   // [cap][tiles][64][8]: the 16x16x32 label fragment (one-hot, <= 16 classes; prop_mask.h)
     uint8_t* cls = nullptr;    // [cap][HWp]
     int cap = 0;
 };
@@ -462,12 +461,8 @@ void launch_prop_mode(const LastProp& lp, const PropArgs& a_in, int mode, hipStr
         else hipLaunchKernelGGL((prop_dense_kernel<true, false>), grid, block, 0, s, a);
     } else {
         if (lp.lab_lo) hipLaunchKernelGGL((prop_dense_kernel<false, true>), grid, block, 0, s, a);
-        else if (lp.no_l) {      // the mask-only form: prop_mask16.h (16x16x32 MFMAs, <= 16 classes) or prop_mask.h
-            static const int m16_env = getenv("VOSPROP_MASK16") ? atoi(getenv("VOSPROP_MASK16")) : 1;
-            if (m16_env && a.d <= kM16MaxClasses) {
-                if (e0) hipExtLaunchKernelGGL(prop_mask16_kernel, grid, block, 0, s, e0, e1, 0, a);
-                else hipLaunchKernelGGL(prop_mask16_kernel, grid, block, 0, s, a);
-            } else if (e0) hipExtLaunchKernelGGL(prop_mask_kernel, grid, block, 0, s, e0, e1, 0, a);
+        else if (lp.no_l) {      // the mask-only form (prop_mask.h)
+            if (e0) hipExtLaunchKernelGGL(prop_mask_kernel, grid, block, 0, s, e0, e1, 0, a);
             else hipLaunchKernelGGL(prop_mask_kernel, grid, block, 0, s, a);
         } else if (e0) hipExtLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, e0, e1, 0, a);
         else hipLaunchKernelGGL((prop_dense_kernel<false, false>), grid, block, 0, s, a);
@@ -627,7 +622,8 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         lp.sel.thr_grp = ctx->tk_thr; lp.sel.thr_elem = ctx->tk_thr_elem; lp.sel.bitmap = ctx->tk_bitmap;
     }
     lp.materialise = ctx->cfg.materialise != 0;
-    lp.no_l = ctx->mask_only && !prob && !lab_lo && !topk && !f32 && !lp.materialise && plan->steps_per_wg <= kMaskMaxSteps;
+    lp.no_l = ctx->mask_only && !prob && !lab_lo && !topk && !f32 && !lp.materialise && plan->steps_per_wg <= kMaskMaxSteps &&
+              d <= kMaskMaxClasses;      // (more classes or longer segments: prop_dense_kernel, with its denominators)
     if (lp.no_l) {
         rc = build_target_consts(ctx, sigma1, sigma2, temperature);
         if (rc) return rc;

@@ -530,3 +530,30 @@ def test_mask_only_step_at_720p_matches_the_oracle(vos, dev):
         checked += int(clear.sum())
     assert checked > 1000
     assert len(np.unique(cls_hist[18])) >= 3
+
+
+def test_mask_only_steps_with_more_than_16_classes_take_the_dense_kernel(vos, dev):
+    """prop_mask_kernel's label product is one 16x16x32 MFMA per column block: 16 classes.  A video with more objects keeps working -
+    the engine launches prop_dense_kernel for its mask-only steps too (vosprop_stats.kernel_id says so) and the masks are those of
+    the steps that return predictions, bit for bit (the same kernel)."""
+    H, W = 96, 136
+    Hd, Wd = vos.feature_map_size(H, W)
+    rs = np.random.RandomState(11)
+    ann = (np.arange(H * W).reshape(H, W) // 653 % 20).astype(np.uint8)        # 20 classes in stripes
+    assert ann.max() == 19
+    feats = [torch.from_numpy(rs.randn(256, Hd, Wd).astype(np.float32) * 0.25).to(dev) for _ in range(6)]
+    out = {}
+    for want_pred in (True, False):
+        eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=9)
+        eng.begin_video(ann)
+        ms = []
+        for f in feats:
+            _, m = eng.step(f, want_pred=want_pred, want_mask=True)
+            if m is not None:
+                ms.append(m.cpu())
+        st = eng.last_stats()
+        eng.close()
+        assert st['kernel_id'] == vos._native.KERNEL_DENSE, st
+        out[want_pred] = ms
+    assert all(torch.equal(a, b) for a, b in zip(out[True], out[False]))
+    assert len(torch.unique(out[False][-1])) > 10

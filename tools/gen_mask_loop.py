@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Generator of the hand-ordered tile loop of `prop_mask_kernel` (csrc/prop_mask.h): writes csrc/prop_mask_loop.inc.
+"""Generator of the hand-ordered tile loop of `prop_mask_kernel` (csrc/prop_mask.h) on v_mfma_f32_16x16x32_bf16: writes
+csrc/prop_mask_loop.inc.
 
-The loop is ONE instruction stream per wave role, emitted as text for a single `asm volatile` statement with a FIXED register
-map (every operand of the statement is bound to the physical registers named here, `"+{v[128:143]}"(S0)` ...): hipcc allocates
-nothing inside it, schedules nothing inside it and inserts no waits or hazard pads - this file does, and checks what it did:
+The loop is ONE instruction stream per wave role, emitted as text for a single `asm volatile` statement per segment with a FIXED
+register map (every operand of the statement is bound to the physical registers named here): hipcc allocates nothing inside it,
+schedules nothing inside it and inserts no waits or hazard pads - this file does, and checks what it did:
 
   * `s_waitcnt lgkmcnt(N)` come from a model of the in-order LDS return queue (every ds_read of the stream is named; a consumer
     waits for exactly the reads issued before its operand's);
@@ -11,19 +12,26 @@ nothing inside it, schedules nothing inside it and inserts no waits or hazard pa
     VALU result -> MFMA operand, transcendental result -> VALU, M0 write -> LDS-DMA) are counted on the steady-state stream and
     the generator FAILS if a distance is below the (conservative) table in HAZ_* below.
 
-One step (tile q of the segment; S = scores being accumulated, P = scores of tile q-1, slots = LDS ring of 6 x 20 KiB):
+Why 16x16x32: the chip is POWER-bound under this kernel (profiles/r04_mask_kernel_ablations.txt: the bare score-MFMA chain alone
+takes 144 us of a 194 us launch on random data, 115 us on zeros), and the 16x16x32 shape moves half the accumulator bytes per MAC
+of 32x32x16 - the same chain as 16x16x32 instructions ran in 127 us (cdna guide rule 28, MI355X_MICROARCH 'DVFS give-back' 7).
+
+A wave owns 32 target columns = two column blocks cb of 16; a reference tile of 32 rows = two row blocks rb; K = 256 = eight
+K-steps of 32.  One step (tile q of the segment; S[rb][cb] = 4 registers; P = scores of tile q-1; ring of 6 LDS slots):
 
     boundary   exit if the alarm of tile q-2 fired (vcc, set in step q-1) or the step counter ran out
-    gap g      v_mfma S += A[g] B[g]        (g = 0: C operand = LM, the prior tile in log2 units minus the running reference)
-               ds_read_b128 A[g & 7]        (second half of tile q, then the first half of tile q+1)
-               v_exp_f32 of one or two rows of P,  every other gap a v_cvt_pk_bf16_f32 (pk of tile q-1) and, in gaps 1-8, the
+    gap g      (ks, rb) = (g >> 1, g & 1):  two MFMAs  S[rb][cb] += A(rb, ks) B[cb][ks], cb = 0, 1  (ks = 0: C operand = LM[rb][cb],
+               the prior tile in log2 units minus the column's reference level)
+               ds_read_b128 A[g & 7]        (second half of tile q's fragments, then the first half of tile q+1's)
+               v_exp_f32 of one or two values of P, every other gap a v_cvt_pk_bf16_f32 (pk of tile q-1) and, in gaps 1-8, the
                running maximum of P (v_max3_f32; the alarm compare sits in gap 9)
-    gaps 1,2   the two label MFMAs of tile q-2 (pk and label fragments were completed in step q-1)
-    gap 0      two v_readlane: the step's control-table entry (LDS-DMA source offsets of tile q+3, flags of tile q+1)
-    gaps 4..   the wave's LDS-DMA pieces of tile q+3 (s_add m0 + global_load_lds_dwordx4, no vector arithmetic)
-    gap 3/10   coordinates of tile q+1 -> registers; if tile q+1 opens a pixel tile or a sigma class, ONE extra MFMA rebuilds LM
-    gap 12,13  label fragments of tile q-1 -> registers
-    end        s_waitcnt vmcnt(own pieces of this step) ; s_barrier
+    gaps 1,2   the two label MFMAs of tile q-2 (one per column block; pk and the label fragment were completed in step q-1)
+    gap 0      two v_readlane: the step's control-table entry (LDS-DMA source offsets of tile q+AHEAD, flags of tile q+1)
+    gaps 4..   the wave's LDS-DMA pieces of tile q+AHEAD (s_add m0 + global_load_lds_dwordx4, no vector arithmetic)
+    gap 3/10   coordinates of tile q+1 -> registers; if tile q+1 opens a pixel tile or a sigma class, FOUR MFMAs rebuild LM
+    gap 12     label fragment of tile q-1 -> registers
+    barrier    s_waitcnt vmcnt(own younger pieces) ; s_barrier - at the step end (waves 0-3) or after gap 7 (waves 4-7: the two
+               waves of a SIMD then sit half a step apart)
 
 Usage: python tools/gen_mask_loop.py [--check]      (--check: regenerate in memory and compare with the committed file)
 """
@@ -35,41 +43,42 @@ ROOT = Path(__file__).resolve().parent.parent
 OUT = ROOT / 'semi-supervised-vos_amd' / 'csrc' / 'prop_mask_loop.inc'
 
 # ---- geometry (must match csrc/prop_mask.h) ----
-SLOT = 20480            # bytes per ring slot: 17 KiB padded feature image, 1 KiB coordinates, 2 KiB labels
-NSLOT = 6
-OFF_COORD = 17408
+ROWB = 544              # padded LDS row of the feature image: 16-B slot = (2 row + k block) mod 16 -> conflict-free ds_read_b128
+OFF_COORD = 17408       # 32 rows x 544 B = 17 KiB exactly
 OFF_LAB = 18432
+SLOT = 19456            # bytes per ring slot: 17 KiB feature image, 1 KiB coordinates, 1 KiB labels (16 classes x 32 rows)
+NSLOT = 6
 ALARM = 100.0           # a weighted exponent above this leaves the loop for the rescale path (prop_mask.h kMaskAlarm)
 
 # ---- register map ----
-V_B = 64                # v[64:127]   target fragments B[ks] = v[64+4ks : 67+4ks]
-V_S = (128, 144)        # v[128:143] S0, v[144:159] S1
-V_Y = 160               # v[160:175]
-V_LM = 176              # v[176:191]
-V_A = 192               # v[192:223]  A[i] = v[192+4i : 195+4i]
-V_PK = (224, 232)       # v[224:231] pk of even tiles, v[232:239] pk of odd tiles
-V_LAB = 240             # v[240:243] rows 0-15, v[244:247] rows 16-31
-V_CA = 248              # v[248:251] coordinate fragment (temporary)
-V_CB = (56, 60)         # v[56:59] target-side prior constants sigma1, v[60:63] sigma2
-V_Q = 52                # v[52:55] exponentials waiting for their packing (temporaries)
-V_MX = 51
-V_TA, V_TB = 49, 50     # control table columns (one entry per lane)
-V_ROWLO, V_ROWHI, V_LANELO, V_LANEHI = 44, 45, 46, 47
-V_SRCA, V_SRCB, V_SRC3 = 40, 41, 42
-V_TABA, V_TABB = 43, 48  # LDS byte offsets of the lane's control-table entry (TA column / this wave's TB column)
-V_AUX = 32              # v[32:39]: g Q_t c of sigma1, sigma2; the column's reference level M; five temporaries
-V_KQ = (32, 33)
-V_MC = 34
-TEMPS = [52, 53, 54, 55, 248, 249, 250, 251, 35, 36, 37, 38, 39]      # free between steps (q registers, coordinate fragment, AUX)
+V_AUX = 24              # v[24:31]: g Q_t c [sigma][cb] (4), the columns' reference levels M [cb] (2), two temporaries
+V_KQ = 24               # KQ[sig][cb] = 24 + 2 sig + cb
+V_MC = 28               # MC[cb] = 28 + cb
+V_CTL = 32              # v[32:47]
+V_SRCA, V_SRCB, V_SRC3, V_TABA = 32, 33, 34, 35
+V_ROWLO, V_ROWHI, V_LANELO, V_LANEHI = 36, 37, 38, 39
+V_TABB, V_TA, V_TB, V_MX = 40, 41, 42, 43
+V_COORDLO, V_COORDHI = 44, 45
+V_CB = 48               # v[48:63]   CB[sig][cb] = 48 + 8 sig + 4 cb : target-side prior constants
+V_B = 64                # v[64:127]  B[cb][ks] = 64 + 32 cb + 4 ks
+V_S = (128, 144)        # S0, S1: S[rb][cb] = base + 8 rb + 4 cb
+V_Y = 160               # v[160:167] Y[cb] = 160 + 4 cb
+V_Q = 168               # v[168:171] exponentials waiting for their packing
+V_LM = 176              # v[176:191] LM[rb][cb] = 176 + 8 rb + 4 cb
+V_A = 192               # v[192:223] A[i] = 192 + 4 i
+V_PK = (224, 232)       # pk of even / odd tiles: + 4 cb + 2 rb + (i >> 1)
+V_LAB = 240             # v[240:243]
+V_CA = 248              # v[248:255] CA[rb] = 248 + 4 rb
+TEMPS = [172, 173, 174, 175, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254, 255, 46, 47, 30, 31]
 # scalar registers of the statement (clobbers)
 S_Q, S_PHASE, S_CNT, S_IDX, S_TBASE, S_CENT, S_TMP, S_TMP2 = 70, 71, 72, 73, 74, 75, 76, 77
-S_HMASK = 78            # s[78:79] lanes 32-63
+S_HMASK = 78            # s[78:79] lanes 16-31 (k block 1: they hold K channels 8-15 of the prior MFMA's B operand)
 S_C7FFF, S_CHI16 = 80, 81
-S_WD = 82                # passes through the control block (every pass runs >= 1 step: more than n + 4 means a logic error)
+S_WD = 82               # passes through the control block (every pass runs >= 1 step: more than n + 4 means a logic error)
 S_RAWA, S_OFFB, S_OFFA = 84, 85, 86
 S_BA = 88               # s[88:89] feature base + tile offset
 S_BC = 90               # s[90:91] third-piece base + tile offset
-TAB_ENTRY = 16          # bytes per control-table entry in LDS: TA, coordinate offset, label offset, pad
+TAB_ENTRY = 16          # bytes per control-table entry in LDS: TA, coordinate offset, label offset, feature offset
 TAB_BLOCK = 64
 AHEAD = 3               # default look-ahead of the LDS-DMA staging in tiles (option 'ahead': 3 or 4 with the six-slot ring)
 
@@ -125,14 +134,23 @@ class Stream:
         del self.fifo[: i + 1]
 
 
-def row_addr(slot, ks):
+def row_addr(slot, rb, ks):
     reg = V_ROWLO if slot < 3 else V_ROWHI
-    return reg, (slot % 3) * SLOT + ks * 32
+    return reg, (slot % 3) * SLOT + rb * 16 * ROWB + ks * 64
 
 
 def lane_addr(slot, off):
     reg = V_LANELO if slot < 3 else V_LANEHI
     return reg, (slot % 3) * SLOT + off
+
+
+def coord_addr(slot, rb):
+    reg = V_COORDLO if slot < 3 else V_COORDHI
+    return reg, (slot % 3) * SLOT + OFF_COORD + rb * 256
+
+
+def s_reg(base, rb, cb):
+    return base + 8 * rb + 4 * cb
 
 
 def gen_step(st, k, tag):
@@ -143,34 +161,27 @@ def gen_step(st, k, tag):
     pk_w, pk_r = V_PK[(k + 1) % 2], V_PK[k % 2]
     o = st.opts
     e = st.emit
+    ab = o.get('ablate', ())      # timing experiments only (results are garbage): tools/mask_variants.sh
 
-    ab = o.get('ablate', ())      # timing experiments only (results are garbage): tools/mask_ablate.sh
-
-    def mfma(dst, a, b, c, reads_extra=()):
-        if 'no_mfma' in ab and dst in V_S:
+    def mfma(dst, a, b, c):
+        if 'no_mfma' in ab and (V_S[0] <= dst < V_S[1] + 16):
             return
-        if 'no_lab' in ab and dst == V_Y:
+        if 'no_lab' in ab and (V_Y <= dst < V_Y + 8):
             return
-        if 'm16' in ab and dst in V_S:
-            # timing experiment: the same MACs as two v_mfma_f32_16x16x32_bf16 (4-register accumulators; results are garbage)
-            for half in range(2):
-                d4 = vr(dst + 4 * half, 4)
-                e(f'v_mfma_f32_16x16x32_bf16 {d4}, {vr(a, 4)}, {vr(b, 4)}, {d4}', 'mfma', reads=set(regs(a, 4)) | set(regs(b, 4)),
-                  writes=regs(dst + 4 * half, 4))
-            return
-        ctext = '0' if c is None else vr(c, 16)
-        rd = set(regs(a, 4)) | set(regs(b, 4)) | (set(regs(c, 16)) if c is not None else set())
-        e(f'v_mfma_f32_32x32x16_bf16 {vr(dst, 16)}, {vr(a, 4)}, {vr(b, 4)}, {ctext}', 'mfma', reads=rd, writes=regs(dst, 16))
+        ctext = '0' if c is None else vr(c, 4)
+        rd = set(regs(a, 4)) | set(regs(b, 4)) | (set(regs(c, 4)) if c is not None else set())
+        e(f'v_mfma_f32_16x16x32_bf16 {vr(dst, 4)}, {vr(a, 4)}, {vr(b, 4)}, {ctext}', 'mfma', reads=rd, writes=regs(dst, 4))
 
     def vexp(q, r):
         if 'no_valu' in ab:
             return
         e(f'v_exp_f32 v{V_Q + q}, v{P + r}', 'trans', reads=[P + r], writes=[V_Q + q])
 
-    def vcvt(i, qa, qb):
+    def vcvt(p, qa, qb):      # pair p = P registers 2p, 2p+1 = (rb, cb, i) with rb = p >> 2, cb = (p >> 1) & 1, i = 2 (p & 1)
         if 'no_valu' in ab:
             return
-        e(f'v_cvt_pk_bf16_f32 v{pk_w + i}, v{V_Q + qa}, v{V_Q + qb}', 'valu', reads=[V_Q + qa, V_Q + qb], writes=[pk_w + i])
+        dst = pk_w + 4 * ((p >> 1) & 1) + 2 * (p >> 2) + (p & 1)
+        e(f'v_cvt_pk_bf16_f32 v{dst}, v{V_Q + qa}, v{V_Q + qb}', 'valu', reads=[V_Q + qa, V_Q + qb], writes=[dst])
 
     def vmax(i):
         if 'no_valu' in ab:
@@ -187,7 +198,7 @@ def gen_step(st, k, tag):
             return '%[ldsa]', stg * SLOT + 8192, V_SRCB, S_BA
         return '%[lds3]', stg * SLOT, V_SRC3, S_BC
 
-    def piece_m0(i):          # M0 = LDS destination; written ahead of the gap's MFMA so that no s_nop is needed in front of the DMA
+    def piece_m0(i):          # M0 = LDS destination; written ahead of the gap's MFMAs so that no s_nop is needed in front of the DMA
         if 'no_dma' in ab:
             return
         m0_base, m0_imm, _, _ = piece_args(i)
@@ -205,25 +216,23 @@ def gen_step(st, k, tag):
     e(f's_sub_u32 s{S_CNT}, s{S_CNT}, 1', 's')
     e(f's_cbranch_scc1 LX{k}_{tag}', 'branch')
 
-    # rows of the previous tile: exponentials (q register rotates over 4), packings, running maximum
+    # values of the previous tile: exponentials (q register rotates over 4), packings, running maximum
     exp_rows = {1: [0], 2: [1], 3: [2], 4: [3], 5: [4], 6: [5], 7: [6], 8: [7], 9: [8], 10: [9], 11: [10], 12: [11],
                 13: [12, 13], 14: [14, 15]}
-    cvt_at = {3: 0, 5: 1, 7: 2, 9: 3, 11: 4, 13: 5, 14: 6, 15: 7}       # packing i = rows 2i, 2i+1
+    cvt_at = {3: 0, 5: 1, 7: 2, 9: 3, 11: 4, 13: 5, 14: 6, 15: 7}       # packing p = P registers 2p, 2p+1
     max_at = {g: g - 1 for g in range(1, 9)}
     npieces = st.role_pieces
     dma_gaps = o.get('dma_gaps', {3: [4, 8, 12], 2: [5, 11]})[npieces]
-
     bar_gap = o.get('skew_gap', 7) if (o.get('skew', True) and npieces == 2) else 15
     for g in range(16):
+        ks, rb = g >> 1, g & 1
         if g in dma_gaps:
             piece_m0(dma_gaps.index(g))
-        # the fragment this MFMA consumes
-        st.wait_for(f'A{g & 7}')
-        mfma(S, V_A + 4 * (g & 7), V_B + 4 * g, V_LM if g == 0 else S)
-        if g < 8:
-            reg, off = row_addr(cur, g + 8)
-        else:
-            reg, off = row_addr(nxt, g - 8)
+        st.wait_for(f'A{g & 7}')           # the fragment this gap's MFMAs consume
+        for cb in range(2):
+            mfma(s_reg(S, rb, cb), V_A + 4 * (g & 7), V_B + 32 * cb + 4 * ks, s_reg(V_LM, rb, cb) if ks == 0 else s_reg(S, rb, cb))
+        f = g + 8 if g < 8 else g - 8      # fragment (ks, rb) = (f >> 1, f & 1) of this tile (g < 8) / of the next one
+        reg, off = row_addr(cur if g < 8 else nxt, f & 1, f >> 1)
         if 'no_ds' not in ab:
             st.ds_read(f'A{g & 7}', V_A + 4 * (g & 7), 4, reg, off)
         if g == 0:
@@ -232,20 +241,20 @@ def gen_step(st, k, tag):
                 e(f'v_readlane_b32 s{S_OFFB}, v{V_TB}, s{S_IDX}', 'valu')
             e(f's_add_u32 s{S_IDX}, s{S_IDX}, 1', 's')
         if g == 1:
-            st.wait_for('LAB0')
+            st.wait_for('LAB')
             mfma(V_Y, V_LAB, pk_r, V_Y)
             e(f's_and_b32 s{S_OFFA}, s{S_RAWA}, 0xfffffff0', 's')
         if g == 2:
-            st.wait_for('LAB1')
-            mfma(V_Y, V_LAB + 4, pk_r + 4, V_Y)
+            mfma(V_Y + 4, V_LAB, pk_r + 4, V_Y + 4)
             e(f's_add_u32 s{S_BA}, %[fb_lo], s{S_OFFA}', 's')
             e(f's_addc_u32 s{S_BA + 1}, %[fb_hi], 0', 's')
             if npieces == 3:
                 e(f's_add_u32 s{S_BC}, %[tb_lo], s{S_OFFB}', 's')
                 e(f's_addc_u32 s{S_BC + 1}, %[tb_hi], 0', 's')
         if g == 3:
-            reg, off = lane_addr(nxt, OFF_COORD)
-            st.ds_read('CA', V_CA, 4, reg, off)
+            for r2 in range(2):
+                reg, off = coord_addr(nxt, r2)
+                st.ds_read(f'CA{r2}', V_CA + 4 * r2, 4, reg, off)
         if g in dma_gaps:
             piece_dma(dma_gaps.index(g))
         for r in exp_rows.get(g, []):
@@ -253,30 +262,29 @@ def gen_step(st, k, tag):
         if g in max_at:
             vmax(max_at[g])
         if g in cvt_at:
-            i = cvt_at[g]
-            vcvt(i, (2 * i) % 4, (2 * i + 1) % 4)
+            p = cvt_at[g]
+            vcvt(p, (2 * p) % 4, (2 * p + 1) % 4)
         if g == 9:
             e(f'v_cmp_lt_f32_e32 vcc, 0x{float_bits(ALARM):08x}, v{V_MX}', 'valu', reads=[V_MX])
-        if g == 10 and 'no_lm' in ab:
-            st.wait_for('CA')
-        if g == 10 and 'no_lm' not in ab:
-            # tile q+1 opens a pixel tile or a sigma class: its prior tile LM = coordinates x target-side constants (one MFMA)
-            st.wait_for('CA')
-            e(f's_bitcmp1_b32 s{S_RAWA}, 0', 's')
-            e(f's_cbranch_scc0 LW{k}_{tag}', 'branch')
-            e(f's_bitcmp1_b32 s{S_RAWA}, 1', 's')
-            e(f's_cbranch_scc1 LV{k}_{tag}', 'branch')
-            mfma(V_LM, V_CA, V_CB[0], None)
-            e(f's_branch LW{k}_{tag}', 'branch')
-            st.label(f'LV{k}_{tag}')
-            mfma(V_LM, V_CA, V_CB[1], None)
-            st.label(f'LW{k}_{tag}')
+        if g == 10:
+            # tile q+1 opens a pixel tile or a sigma class: its prior tile LM[rb][cb] = coordinates x target-side constants
+            st.wait_for('CA1')
+            if 'no_lm' not in ab:
+                e(f's_bitcmp1_b32 s{S_RAWA}, 0', 's')
+                e(f's_cbranch_scc0 LW{k}_{tag}', 'branch')
+                e(f's_bitcmp1_b32 s{S_RAWA}, 1', 's')
+                e(f's_cbranch_scc1 LV{k}_{tag}', 'branch')
+                for sg in range(2):
+                    if sg == 1:
+                        e(f's_branch LW{k}_{tag}', 'branch')
+                        st.label(f'LV{k}_{tag}')
+                    for r2 in range(2):
+                        for cb in range(2):
+                            mfma(s_reg(V_LM, r2, cb), V_CA + 4 * r2, V_CB + 8 * sg + 4 * cb, None)
+                st.label(f'LW{k}_{tag}')
         if g == 12 and 'no_lab' not in ab:
             reg, off = lane_addr(prv, OFF_LAB)
-            st.ds_read('LAB0', V_LAB, 4, reg, off)
-        if g == 13 and 'no_lab' not in ab:
-            reg, off = lane_addr(prv, OFF_LAB + 1024)
-            st.ds_read('LAB1', V_LAB + 4, 4, reg, off)
+            st.ds_read('LAB', V_LAB, 4, reg, off)
         if g == bar_gap:
             # own pieces of tile q+2 (issued in step q+2-ahead) have landed, younger ones fly on; the barrier publishes every wave's.
             # (Role B with 'skew': in the middle of its step - the two waves of a SIMD then sit half a step apart.)
@@ -294,67 +302,71 @@ def float_bits(x):
 
 def gen_rescale(par, tag):
     """Rescale path at a step boundary for the pending tile q-2 of parity `par` (its scores S[par] are intact, its label product
-    has not run; prop_mask.h has the derivation).  Straight-line vector code, rare."""
+    has not run; prop_mask.h has the derivation), column block by column block.  Straight-line vector code, rare."""
     Sx, Sn, PKw = V_S[par], V_S[1 - par], V_PK[par]
     T = TEMPS
     o = []
     a = o.append
-    a(f'v_max3_f32 v{T[0]}, v{Sx}, v{Sx + 1}, v{Sx + 2}')
-    a(f'v_max3_f32 v{T[1]}, v{Sx + 3}, v{Sx + 4}, v{Sx + 5}')
-    a(f'v_max3_f32 v{T[2]}, v{Sx + 6}, v{Sx + 7}, v{Sx + 8}')
-    a(f'v_max3_f32 v{T[3]}, v{Sx + 9}, v{Sx + 10}, v{Sx + 11}')
-    a(f'v_max3_f32 v{T[4]}, v{Sx + 12}, v{Sx + 13}, v{Sx + 14}')
-    a(f'v_max3_f32 v{T[0]}, v{T[0]}, v{T[1]}, v{T[2]}')
-    a(f'v_max3_f32 v{T[3]}, v{T[3]}, v{T[4]}, v{Sx + 15}')
-    a(f'v_max_f32 v{T[0]}, v{T[0]}, v{T[3]}')
-    # the two half-waves share a column: max with the partner lane (lane ^ 32)
-    a(f'v_mov_b32 v{T[1]}, v{T[0]}')
-    a('s_nop 1')
-    a(f'v_permlane32_swap_b32 v{T[0]}, v{T[1]}')
-    a('s_nop 1')
-    a(f'v_max_f32 v{T[0]}, v{T[0]}, v{T[1]}')                      # xm
-    a(f's_cmp_eq_u32 s{S_CENT}, 0')
-    a(f's_cbranch_scc1 LRF{par}_{tag}')                            # first tile of the segment: shift = xm, Y is still 0
-    a(f'v_cmp_lt_f32_e32 vcc, 0x{float_bits(ALARM):08x}, v{T[0]}')
-    a(f'v_cndmask_b32_e32 v{T[0]}, 0, v{T[0]}, vcc')               # shift = this column alarmed ? xm : 0
-    a(f'v_exp_f32_e64 v{T[1]}, -v{T[0]}')
-    a('s_nop 1')
-    for r in range(16):
-        a(f'v_mul_f32_e32 v{V_Y + r}, v{V_Y + r}, v{T[1]}')
-    a(f'LRF{par}_{tag}:')
-    for i in range(8):                                             # weights of the pending tile against the new level
-        a(f'v_sub_f32_e32 v{T[2]}, v{Sx + 2 * i}, v{T[0]}')
-        a(f'v_sub_f32_e32 v{T[3]}, v{Sx + 2 * i + 1}, v{T[0]}')
-        a(f'v_exp_f32_e32 v{T[2]}, v{T[2]}')
-        a(f'v_exp_f32_e32 v{T[3]}, v{T[3]}')
+    for cb in range(2):
+        v = [s_reg(Sx, rb, cb) + i for rb in range(2) for i in range(4)]      # the lane's 8 values of this column
+        a(f'v_max3_f32 v{T[0]}, v{v[0]}, v{v[1]}, v{v[2]}')
+        a(f'v_max3_f32 v{T[1]}, v{v[3]}, v{v[4]}, v{v[5]}')
+        a(f'v_max3_f32 v{T[0]}, v{T[0]}, v{T[1]}, v{v[6]}')
+        a(f'v_max_f32 v{T[0]}, v{T[0]}, v{v[7]}')
+        # a column lives on four lanes (k blocks): lane ^ 16, then lane ^ 32
+        a(f'v_mov_b32 v{T[1]}, v{T[0]}')
         a('s_nop 1')
-        a(f'v_cvt_pk_bf16_f32 v{PKw + i}, v{T[2]}, v{T[3]}')
-    for r in range(16):                                            # tile q-1 sits on the old LM; LM of the tiles to come
-        a(f'v_sub_f32_e32 v{Sn + r}, v{Sn + r}, v{T[0]}')
-        a(f'v_sub_f32_e32 v{V_LM + r}, v{V_LM + r}, v{T[0]}')
-    a(f'v_add_f32_e32 v{V_MC}, v{V_MC}, v{T[0]}')
-    # K channels 12-14 of the target-side constants (lanes of the upper k half): 3-way bf16 split of -(g Q_t c + M)
-    for sg in range(2):
-        cb = V_CB[sg]
-        x, h, m, l, t = T[1], T[2], T[4], T[5], T[3]
-        a(f'v_add_f32_e32 v{x}, v{V_KQ[sg]}, v{V_MC}')
-        a(f'v_mul_f32_e32 v{x}, -1.0, v{x}')
-        a(f'v_bfe_u32 v{h}, v{x}, 16, 1')
-        a(f'v_add3_u32 v{h}, v{x}, v{h}, s{S_C7FFF}')
-        a(f'v_and_b32_e32 v{h}, 0xffff0000, v{h}')
-        a(f'v_sub_f32_e32 v{t}, v{x}, v{h}')
-        a(f'v_bfe_u32 v{m}, v{t}, 16, 1')
-        a(f'v_add3_u32 v{m}, v{t}, v{m}, s{S_C7FFF}')
-        a(f'v_and_b32_e32 v{m}, 0xffff0000, v{m}')
-        a(f'v_sub_f32_e32 v{t}, v{t}, v{m}')
-        a(f'v_bfe_u32 v{l}, v{t}, 16, 1')
-        a(f'v_add3_u32 v{l}, v{t}, v{l}, s{S_C7FFF}')
-        a(f'v_lshrrev_b32_e32 v{h}, 16, v{h}')
-        a(f'v_or_b32_e32 v{h}, v{h}, v{m}')                                         # elements 4, 5 = (hi part, mid part)
-        a(f'v_lshrrev_b32_e32 v{l}, 16, v{l}')
-        a(f'v_and_or_b32 v{l}, v{cb + 3}, s{S_CHI16}, v{l}')                        # element 6 = low part, element 7 stays (-1e30)
-        a(f'v_cndmask_b32_e64 v{cb + 2}, v{cb + 2}, v{h}, s[{S_HMASK}:{S_HMASK + 1}]')
-        a(f'v_cndmask_b32_e64 v{cb + 3}, v{cb + 3}, v{l}, s[{S_HMASK}:{S_HMASK + 1}]')
+        a(f'v_permlane16_swap_b32 v{T[0]}, v{T[1]}')
+        a('s_nop 1')
+        a(f'v_max_f32 v{T[0]}, v{T[0]}, v{T[1]}')
+        a(f'v_mov_b32 v{T[1]}, v{T[0]}')
+        a('s_nop 1')
+        a(f'v_permlane32_swap_b32 v{T[0]}, v{T[1]}')
+        a('s_nop 1')
+        a(f'v_max_f32 v{T[0]}, v{T[0]}, v{T[1]}')                      # xm
+        a(f's_cmp_eq_u32 s{S_CENT}, 0')
+        a(f's_cbranch_scc1 LRF{par}{cb}_{tag}')                        # first tile of the segment: shift = xm, Y is still 0
+        a(f'v_cmp_lt_f32_e32 vcc, 0x{float_bits(ALARM):08x}, v{T[0]}')
+        a(f'v_cndmask_b32_e32 v{T[0]}, 0, v{T[0]}, vcc')               # shift = this column alarmed ? xm : 0
+        a(f'v_exp_f32_e64 v{T[1]}, -v{T[0]}')
+        a('s_nop 1')
+        for i in range(4):
+            a(f'v_mul_f32_e32 v{V_Y + 4 * cb + i}, v{V_Y + 4 * cb + i}, v{T[1]}')
+        a(f'LRF{par}{cb}_{tag}:')
+        for pr in range(4):                                            # weights of the pending tile against the new level
+            a(f'v_sub_f32_e32 v{T[2]}, v{v[2 * pr]}, v{T[0]}')
+            a(f'v_sub_f32_e32 v{T[3]}, v{v[2 * pr + 1]}, v{T[0]}')
+            a(f'v_exp_f32_e32 v{T[2]}, v{T[2]}')
+            a(f'v_exp_f32_e32 v{T[3]}, v{T[3]}')
+            a('s_nop 1')
+            a(f'v_cvt_pk_bf16_f32 v{PKw + 4 * cb + pr}, v{T[2]}, v{T[3]}')
+        for rb in range(2):                                            # tile q-1 sits on the old LM; LM of the tiles to come
+            for i in range(4):
+                a(f'v_sub_f32_e32 v{s_reg(Sn, rb, cb) + i}, v{s_reg(Sn, rb, cb) + i}, v{T[0]}')
+                a(f'v_sub_f32_e32 v{s_reg(V_LM, rb, cb) + i}, v{s_reg(V_LM, rb, cb) + i}, v{T[0]}')
+        a(f'v_add_f32_e32 v{V_MC + cb}, v{V_MC + cb}, v{T[0]}')
+        # K channels 12-14 of the target-side constants (lanes of k block 1): 3-way bf16 split of -(g Q_t c + M)
+        for sg in range(2):
+            cbr = V_CB + 8 * sg + 4 * cb
+            x, h, m, l, t = T[1], T[2], T[4], T[5], T[3]
+            a(f'v_add_f32_e32 v{x}, v{V_KQ + 2 * sg + cb}, v{V_MC + cb}')
+            a(f'v_mul_f32_e32 v{x}, -1.0, v{x}')
+            a(f'v_bfe_u32 v{h}, v{x}, 16, 1')
+            a(f'v_add3_u32 v{h}, v{x}, v{h}, s{S_C7FFF}')
+            a(f'v_and_b32_e32 v{h}, 0xffff0000, v{h}')
+            a(f'v_sub_f32_e32 v{t}, v{x}, v{h}')
+            a(f'v_bfe_u32 v{m}, v{t}, 16, 1')
+            a(f'v_add3_u32 v{m}, v{t}, v{m}, s{S_C7FFF}')
+            a(f'v_and_b32_e32 v{m}, 0xffff0000, v{m}')
+            a(f'v_sub_f32_e32 v{t}, v{t}, v{m}')
+            a(f'v_bfe_u32 v{l}, v{t}, 16, 1')
+            a(f'v_add3_u32 v{l}, v{t}, v{l}, s{S_C7FFF}')
+            a(f'v_lshrrev_b32_e32 v{h}, 16, v{h}')
+            a(f'v_or_b32_e32 v{h}, v{h}, v{m}')                                         # elements 4, 5 = (hi part, mid part)
+            a(f'v_lshrrev_b32_e32 v{l}, 16, v{l}')
+            a(f'v_and_or_b32 v{l}, v{cbr + 3}, s{S_CHI16}, v{l}')                       # element 6 = low part, element 7 stays (-1e30)
+            a(f'v_cndmask_b32_e64 v{cbr + 2}, v{cbr + 2}, v{h}, s[{S_HMASK}:{S_HMASK + 1}]')
+            a(f'v_cndmask_b32_e64 v{cbr + 3}, v{cbr + 3}, v{l}, s[{S_HMASK}:{S_HMASK + 1}]')
     return o
 
 
@@ -375,17 +387,28 @@ def gen_role(tag, npieces, opts):
     ahead = opts.get('ahead', AHEAD)
     init = []
     for r in range(16):
-        init += [f'v_mov_b32_e32 v{V_Y + r}, 0', f'v_mov_b32_e32 v{V_PK[0] + r}, 0', f'v_mov_b32_e32 v{V_S[1] + r}, {neg_inf}']
+        init += [f'v_mov_b32_e32 v{V_PK[0] + r}, 0', f'v_mov_b32_e32 v{V_S[1] + r}, {neg_inf}']
     for r in range(8):
+        init.append(f'v_mov_b32_e32 v{V_Y + r}, 0')
+    for r in range(4):
         init.append(f'v_mov_b32_e32 v{V_LAB + r}, 0')
-    init += [f'v_mov_b32_e32 v{V_MX}, {neg_inf}', f'v_mov_b32_e32 v{V_MC}, 0']
-    # fragments ks = 0..7 of tile 0 (slot 0) and its prior tile LM = coordinates x target-side constants of its sigma class
+    init += [f'v_mov_b32_e32 v{V_MX}, {neg_inf}', f'v_mov_b32_e32 v{V_MC}, 0', f'v_mov_b32_e32 v{V_MC + 1}, 0']
+    # fragments 0..7 of tile 0 (slot 0; fragment f = (ks, rb) = (f >> 1, f & 1)) and its prior tile LM[rb][cb] = coordinates x
+    # target-side constants of its sigma class
     for i in range(8):
-        init.append(f'ds_read_b128 {vr(V_A + 4 * i, 4)}, v{V_ROWLO} offset:{i * 32}')
-    init.append(f'ds_read_b128 {vr(V_CA, 4)}, v{V_LANELO} offset:{OFF_COORD}')
-    init += ['s_waitcnt lgkmcnt(0)', f's_cmp_lg_u32 %[sp0], 0', f's_cbranch_scc1 LI2_{tag}',
-             f'v_mfma_f32_32x32x16_bf16 {vr(V_LM, 16)}, {vr(V_CA, 4)}, {vr(V_CB[0], 4)}, 0', f's_branch LI3_{tag}', f'LI2_{tag}:',
-             f'v_mfma_f32_32x32x16_bf16 {vr(V_LM, 16)}, {vr(V_CA, 4)}, {vr(V_CB[1], 4)}, 0', f'LI3_{tag}:', 's_nop 7', 's_nop 7']
+        reg, off = row_addr(0, i & 1, i >> 1)
+        init.append(f'ds_read_b128 {vr(V_A + 4 * i, 4)}, v{reg} offset:{off}')
+    for r2 in range(2):
+        reg, off = coord_addr(0, r2)
+        init.append(f'ds_read_b128 {vr(V_CA + 4 * r2, 4)}, v{reg} offset:{off}')
+    init += ['s_waitcnt lgkmcnt(0)', f's_cmp_lg_u32 %[sp0], 0', f's_cbranch_scc1 LI2_{tag}']
+    for sg in range(2):
+        if sg == 1:
+            init += [f's_branch LI3_{tag}', f'LI2_{tag}:']
+        for r2 in range(2):
+            for cb in range(2):
+                init.append(f'v_mfma_f32_16x16x32_bf16 {vr(s_reg(V_LM, r2, cb), 4)}, {vr(V_CA + 4 * r2, 4)}, {vr(V_CB + 8 * sg + 4 * cb, 4)}, 0')
+    init += [f'LI3_{tag}:', 's_nop 7', 's_nop 7']
     if opts.get('prio_b') is not None and npieces == 2:
         init.append(f"s_setprio {opts['prio_b']}")
     if opts.get('prio_a') is not None and npieces == 3:
@@ -393,7 +416,7 @@ def gen_role(tag, npieces, opts):
     head = init + [
         # ---- segment state ----
         f's_mov_b32 s{S_Q}, 0', f's_mov_b32 s{S_PHASE}, 0', f's_mov_b32 s{S_TBASE}, 0', f's_mov_b32 s{S_CENT}, 0',
-        f's_mov_b32 s{S_HMASK}, 0', f's_mov_b32 s{S_HMASK + 1}, -1',
+        f's_mov_b32 s{S_HMASK}, 0xffff0000', f's_mov_b32 s{S_HMASK + 1}, 0',
         f's_mov_b32 s{S_C7FFF}, 0x7fff', f's_mov_b32 s{S_CHI16}, 0xffff0000',
         f's_add_u32 s{S_WD}, %[n], 4',
         # ---- how many steps until the next event: segment end, control table exhausted, first tile pending ----
@@ -543,29 +566,29 @@ def render(opts):
     # is not an input is initialised INSIDE the statement (zeros, the first tile's fragments and prior tile): the outputs are
     # write-only operands and hipcc never builds a wide register block element by element
     regmap = {
-        'AUX': vr(V_AUX, 8),       # v[32:39]: in g Q_t c (sigma1, sigma2); out the reference level M; temporaries
-        'CTL': vr(V_SRCA, 16),     # v[40:55]: in LDS-DMA lane offsets, LDS address bases, first control-table block; temporaries
-        'CB': vr(V_CB[0], 8),      # v[56:63]: in target-side prior constants of both sigma classes (the rescale path rewrites them)
-        'B0': vr(V_B, 16), 'B1': vr(V_B + 16, 16), 'B2': vr(V_B + 32, 16), 'B3': vr(V_B + 48, 16),      # v[64:127]: in target fragments
-        'S0': vr(V_S[0], 16), 'S1': vr(V_S[1], 16),      # out: scores of the last two tiles
-        'Y': vr(V_Y, 16),          # out: numerators
-        'PK': vr(V_PK[0], 16),     # out: packed weights (even tile | odd tile)
-        'LAB': vr(V_LAB, 8),       # out: label fragments of tile n-2
+        'AUX': vr(V_AUX, 8),       # in g Q_t c [sigma][cb]; out the reference levels M [cb]; temporaries
+        'CTL': vr(V_CTL, 16),      # in LDS-DMA lane offsets, LDS address bases, first control-table block; temporaries
+        'CB': vr(V_CB, 16),        # in target-side prior constants [sigma][cb] (the rescale path rewrites parts of them)
+        'B0': vr(V_B, 16), 'B1': vr(V_B + 16, 16), 'B2': vr(V_B + 32, 16), 'B3': vr(V_B + 48, 16),      # in target fragments [cb][ks]
+        'S0': vr(V_S[0], 16), 'S1': vr(V_S[1], 16),      # out: scores of the last two tiles [rb][cb]
+        'Y': vr(V_Y, 8),           # out: numerators [cb]
+        'PK': vr(V_PK[0], 16),     # out: packed weights (even tile | odd tile) [cb][2 rb + (i >> 1)]
+        'LAB': vr(V_LAB, 4),       # out: label fragment of tile n-2
     }
     for k, v in regmap.items():
         out.append(f'#define VOSPROP_MASK_REG_{k} "{{{v}}}"')
     assert V_PK[1] == V_PK[0] + 8
     for name, reg in (('SRCA', V_SRCA), ('SRCB', V_SRCB), ('SRC3', V_SRC3), ('ROWLO', V_ROWLO), ('ROWHI', V_ROWHI),
                       ('LANELO', V_LANELO), ('LANEHI', V_LANEHI), ('TA', V_TA), ('TB', V_TB), ('MX', V_MX),
-                      ('TABA', V_TABA), ('TABB', V_TABB)):
-        out.append(f'#define VOSPROP_MASK_CTL_{name} {reg - V_SRCA}')
-    out.append(f'#define VOSPROP_MASK_AUX_KQ1 {V_KQ[0] - V_AUX}')
-    out.append(f'#define VOSPROP_MASK_AUX_KQ2 {V_KQ[1] - V_AUX}')
-    out.append(f'#define VOSPROP_MASK_AUX_MC {V_MC - V_AUX}')
+                      ('TABA', V_TABA), ('TABB', V_TABB), ('COORDLO', V_COORDLO), ('COORDHI', V_COORDHI)):
+        out.append(f'#define VOSPROP_MASK_CTL_{name} {reg - V_CTL}')
+    out.append(f'#define VOSPROP_MASK_AUX_KQ {V_KQ - V_AUX}      // + 2 sigma + cb')
+    out.append(f'#define VOSPROP_MASK_AUX_MC {V_MC - V_AUX}      // + cb')
+    out.append(f'#define VOSPROP_MASK_ROWB {ROWB}')
     out.append(f'#define VOSPROP_MASK_TAB_ENTRY {TAB_ENTRY}')
     out.append(f'#define VOSPROP_MASK_TAB_BLOCK {TAB_BLOCK}')
     out.append(f"#define VOSPROP_MASK_AHEAD {opts.get('ahead', AHEAD)}")
-    clob = [f'v{i}' for i in list(range(V_LM, V_LM + 16)) + list(range(V_A, V_A + 32)) + list(range(V_CA, V_CA + 8))]
+    clob = [f'v{i}' for i in list(range(V_Q, V_Q + 8)) + list(range(V_LM, V_LM + 16)) + list(range(V_A, V_A + 32)) + list(range(V_LAB + 4, V_LAB + 16))]
     clob += [f's{i}' for i in range(S_Q, S_BC + 2)]
     out.append('#define VOSPROP_MASK_CLOBBERS ' + ', '.join(f'"{c}"' for c in clob) + ', "vcc", "scc", "memory"')
     # ONE statement per segment holds both roles and the rare paths: %[role] != 0 takes the second stream

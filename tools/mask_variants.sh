@@ -3,7 +3,7 @@
 # options) into build/variants/ - locally, so that they travel to the GPU box with the snapshot.
 #   bash tools/mask_variants.sh name1:"--ablate no_dma" name2:"--opt dma_gaps={3:[2,6,10],2:[3,9]}" ...
 R=$(cd "$(dirname "$0")/.." && pwd)
-GEN=${GEN:-tools/gen_mask16_loop.py}; INCMACRO=${INCMACRO:-VOSPROP_MASK16_LOOP_INC}      # (the 32x32x16 twin: GEN=tools/gen_mask_loop.py INCMACRO=VOSPROP_MASK_LOOP_INC VOSPROP_MASK16=0 at run time)
+GEN=${GEN:-tools/gen_mask_loop.py}; INCMACRO=${INCMACRO:-VOSPROP_MASK_LOOP_INC}
 mkdir -p $R/build/variants
 pids=()
 for spec in "$@"; do
