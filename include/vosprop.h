@@ -213,6 +213,13 @@ typedef struct vosprop_stats {
 #define VOSPROP_KERNEL_TOPK         3   /* prop_dense_kernel<TK 1> + topk_select2 + prop_dense_kernel<TK 2> */
 #define VOSPROP_KERNEL_F32          4   /* prop_f32_kernel (VOSPROP_PREC_F32) */
 #define VOSPROP_KERNEL_MATERIALISED 5   /* prop_dense_kernel<MAT 1> + <MAT 2> (affinity through HBM) */
+/* Top-k variant: the three capacity limits of its kernels are REPORTED, never silent.  out3 = how often, since the context's first
+ * top-k step, (0) a lane ran out of dump slots for a candidate group in the re-scoring pass, (1) a pixel had more than 40 candidate
+ * groups in the combine kernel, (2) a pixel had more than 512 candidate list entries in the select kernel - each drops candidates
+ * (the result is then a lower bound of the exact top-k sum).  All zero on every shape of the test-suite and the bench except the
+ * constructed mass-tie case.  Waits for the work enqueued on `stream`. */
+int vosprop_topk_overflows(vosprop_ctx* ctx, unsigned* out3, void* stream);
+
 /* name of a VOSPROP_KERNEL_* value ("prop_mask_kernel" ...), or "?" */
 const char* vosprop_kernel_name(int kernel_id);
 int vosprop_last_stats(const vosprop_ctx* ctx, vosprop_stats* out);

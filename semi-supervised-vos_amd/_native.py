@@ -68,6 +68,7 @@ SYMBOLS = {
     'vosprop_sample_frames': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     'vosprop_last_stats': (ctypes.c_int, [_vp, ctypes.POINTER(Stats)]),
     'vosprop_kernel_name': (ctypes.c_char_p, [ctypes.c_int]),
+    'vosprop_topk_overflows': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint), _vp]),
     'vosprop_time_last_propagation': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.POINTER(ctypes.c_double)]),
 }
 

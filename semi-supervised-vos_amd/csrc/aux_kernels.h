@@ -385,6 +385,7 @@ struct TopkSelectArgs {
     float* thr_grp;           // [TT*256]
     float* thr_elem;          // [TT*256]
     unsigned* bitmap;         // [TT][words], cleared by pass 1
+    unsigned* over;           // [3] clamp counters (common.h PropArgs.tk_over)
 };
 
 constexpr int kTkSelCols = 8;      // columns (= waves) per block of the select kernel
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(kTkSelCols * 64) void topk_select2_kernel(const Top
             }
             L0 = T;
         }
+        if (n_c > kTkSelCap && lane == 0) atomicAdd(a.over + 2, 1u);      // candidates beyond the LDS carry are dropped: reported
         n_c = n_c < kTkSelCap ? n_c : kTkSelCap;
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
         __builtin_amdgcn_wave_barrier();
@@ -546,6 +548,7 @@ struct TopkCombineArgs {
     int slot[kMaxRef];
     int k, d, HW, HWp, n_ref, chunks, cap;
     float c;
+    unsigned* over;           // [3] clamp counters (common.h PropArgs.tk_over)
     int debug;                // dev switch (VOSPROP_TK_DEBUG): 1 = radix selection on all keys, no lane-maximum bound / compaction
 };
 
@@ -586,6 +589,7 @@ __global__ __launch_bounds__(kTkComWaves * 64) void topk_combine2_kernel(const T
         }
         const int before = incl - cu;
         int total = __shfl(incl, 63);
+        if (total > 4 * kTkComNV && lane == 0) atomicAdd(a.over + 1, 1u);      // groups beyond 40 are dropped: reported
         total = total < 4 * kTkComNV ? total : 4 * kTkComNV;      // (more than 40 groups reach the threshold only under mass ties)
         for (int q = 0; q < cu; ++q)
             if (before + q < 4 * kTkComNV) tab[wv][before + q] = ((unsigned)lane << 8) | (unsigned)q;

@@ -108,6 +108,8 @@ struct PropArgs {
     float* tk_dump;             // [TT*256][2][tk_chunks][tk_cap][16] weighted exponents of the dumped groups
     unsigned* tk_dump_r;        // [TT*256][2][tk_chunks][tk_cap]     their tiles: frame << 16 | pixel tile
     unsigned* tk_cnt;           // [TT*256][2][tk_chunks]             groups dumped
+    unsigned* tk_over;          // [3] capacity clamps that fired since vosprop_begin_video: dump slots of a lane, groups of a pixel in the
+                                //   combine kernel, candidates of a pixel in the select kernel (vosprop_topk_overflows)
     // prop_mask_kernel (prop_mask.h): target-side constants of the prior MFMA, built once per engine (engine.hip build_target_consts)
     const void* tc_b;           // [2 sigma][HWp][2 k halves] bf16x8: B fragment of the prior MFMA with c folded in and the 3-way split of -g Q_t c
     const float* tc_kq;         // [2 sigma][HWp] g Q_t c

@@ -104,6 +104,7 @@ struct vosprop_ctx {
     float* tk_dump = nullptr;      // [TT*256][2][chunks][cap][16]
     unsigned* tk_dump_r = nullptr;
     unsigned* tk_cnt = nullptr;
+    unsigned* tk_over = nullptr;   // [3] capacity-clamp counters of the top-k kernels (vosprop_topk_overflows)
     size_t tk_dump_groups = 0;     // capacity in groups (= TT*256*2*chunks*cap)
     size_t tk_cnt_units = 0;
     // video state
@@ -579,6 +580,10 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         if (need_chunks > 32) return fail(ctx, VOSPROP_E_UNSUPPORTED, "top-k: more than 32 768 reference tiles");
         const size_t cols = (size_t)ctx->TT * kBT;
         const size_t units = cols * 2 * chunks, groups = units * KS;
+        if (!ctx->tk_over) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->tk_over, 3 * sizeof(unsigned)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->tk_over, 0, 3 * sizeof(unsigned), s));
+        }
         if (!ctx->tk_thr) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->tk_thr, cols * sizeof(float)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->tk_thr_elem, cols * sizeof(float)));
@@ -615,11 +620,13 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         a.tk_dump = ctx->tk_dump;
         a.tk_dump_r = ctx->tk_dump_r;
         a.tk_cnt = ctx->tk_cnt;
+        a.tk_over = ctx->tk_over;
         memset(&lp.sel, 0, sizeof(lp.sel));
         lp.sel.part = ctx->tk_part;
         lp.sel.plist_off = plan->d_off;
         lp.sel.k = topk; lp.sel.ks = KS; lp.sel.HW = ctx->HW; lp.sel.bits = bits; lp.sel.words = words;
         lp.sel.thr_grp = ctx->tk_thr; lp.sel.thr_elem = ctx->tk_thr_elem; lp.sel.bitmap = ctx->tk_bitmap;
+        lp.sel.over = ctx->tk_over;
     }
     lp.materialise = ctx->cfg.materialise != 0;
     lp.no_l = ctx->mask_only && !prob && !lab_lo && !topk && !f32 && !lp.materialise && plan->steps_per_wg <= kMaskMaxSteps &&
@@ -667,6 +674,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         memset(&ca, 0, sizeof(ca));
         ca.thr_elem = ctx->tk_thr_elem; ca.dump = ctx->tk_dump; ca.dump_r = ctx->tk_dump_r; ca.cnt = ctx->tk_cnt;
         ca.cls_ring = ring.cls;
+        ca.over = ctx->tk_over;
         ca.norm_part = lp.tk_norm ? ctx->part : nullptr;
         ca.plist_off = plan->d_off;
         ca.norm_rows = 2 + d;
@@ -973,6 +981,7 @@ void vosprop_destroy(vosprop_ctx* ctx) {
     ring_free(ctx->ring);
     ring_free(ctx->scratch);
     if (ctx->coord_tab) (void)hipFree(ctx->coord_tab);
+    if (ctx->tk_over) (void)hipFree(ctx->tk_over);
     if (ctx->tc_b) (void)hipFree(ctx->tc_b);
     if (ctx->tc_kq) (void)hipFree(ctx->tc_kq);
     if (ctx->coord_f32) (void)hipFree(ctx->coord_f32);
@@ -1187,6 +1196,15 @@ int vosprop_predict(vosprop_ctx* ctx, const void* ref_dev, const void* target_de
     if (rc) return rc;
     return propagate(ctx, R, slots, n_ref, frame_idx, n_ref, d, probability != 0, true, sigma1, sigma2, temperature,
                      out_dev, ctx->cls_tmp, nullptr, nullptr, s);
+}
+
+int vosprop_topk_overflows(vosprop_ctx* ctx, unsigned* out3, void* stream) {
+    if (!ctx || !out3) return VOSPROP_E_INVALID;
+    out3[0] = out3[1] = out3[2] = 0u;
+    if (!ctx->tk_over) return VOSPROP_OK;      // no top-k step has run on this context
+    HIP_TRY(ctx, hipMemcpyAsync(out3, ctx->tk_over, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return VOSPROP_OK;
 }
 
 const char* vosprop_kernel_name(int kernel_id) {

@@ -463,6 +463,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
         static_assert(TK == 0 || kStageA, "the top-k passes assume the older-wave staging scheme (their vmcnt counts)");
         auto tk_dump = [&](float x) __attribute__((always_inline)) -> bool {
             const bool hit = x >= tk_thr && tk_cur < A.tk_cap;
+            if (x >= tk_thr && tk_cur >= A.tk_cap) atomicAdd(A.tk_over, 1u);      // a candidate group is DROPPED: reported, never silent
             const bool any = __any(hit);
             if (any) {
                 if (hit) {

@@ -176,6 +176,13 @@ class PropagationEngine:
         out['kernel'] = self._L.vosprop_kernel_name(st.kernel_id).decode()      # what the engine launched (set where it decides)
         return out
 
+    def topk_overflows(self):
+        """(dump slots, combine groups, select candidates): how often a capacity limit of the top-k kernels dropped candidates since
+        the engine's first top-k step (include/vosprop.h vosprop_topk_overflows); waits for the current stream."""
+        out = (ctypes.c_uint * 3)()
+        self._check(self._L.vosprop_topk_overflows(self._ctx, out, _stream_ptr(self.device)), 'vosprop_topk_overflows')
+        return tuple(int(v) for v in out)
+
     def timing_begin(self):
         """Start bracketing every dense propagation-kernel launch with HIP events on its stream (in-situ timing)."""
         self._check(self._L.vosprop_timing_begin(self._ctx), 'vosprop_timing_begin')

@@ -142,4 +142,36 @@ def test_topk_mass_ties_take_the_fallback_and_stay_finite(vos, dev):
     assert np.all(np.isfinite(a)) and np.all(a >= 0)
     assert np.all(a.sum(0) <= b.sum(0) * (1 + 1e-3) + 1e-9)
     assert a.sum() > 0
+    # the capacity clamps are REPORTED (vosprop_topk_overflows), never silent: here none fires (the spatial prior breaks the ties of the
+    # scores - only the frames of one sigma class tie, five ways), so the kept set is exact and the counters read zero
+    over = e_k.topk_overflows()
+    assert len(over) == 3 and over == (0, 0, 0), over
     e_k.close(); e_d.close()
+
+
+@pytest.mark.parametrize('k', [20, 32])
+def test_topk_capacity_clamps_do_not_fire_on_flat_logits(vos, dev, k):
+    """The three capacity limits of the top-k kernels (dump slots per lane, 40 groups per pixel in the combine kernel, 512
+    candidates per pixel in the select kernel) drop candidates when they fire.  On flat, slowly varying logits at 480p - many near-equal
+    group maxima, the hard case short of exact ties - with the LARGEST k (32: room for only 8 extra groups) they must not fire
+    (vosprop_topk_overflows == 0), and the prediction must be the oracle's top-k restatement on a column sample."""
+    Hd, Wd, T, d, fi = 60, 107, 7, 4, 6
+    HW = Hd * Wd
+    rs = np.random.RandomState(5 + k)
+    low = rs.randn(T, 256, 8, 14).astype(np.float32)
+    feats = torch.nn.functional.interpolate(torch.from_numpy(low), size=(Hd, Wd), mode='bilinear', align_corners=False).numpy()
+    feats = bf16_round(feats * 0.2 + rs.randn(T, 256, Hd, Wd).astype(np.float32) * 0.02)       # smooth + a little texture
+    lab = rs.randint(0, d, size=(T, HW))
+    oh = np.zeros((d, T, HW), np.float32)
+    tt, pp = np.meshgrid(np.arange(T), np.arange(HW), indexing='ij')
+    oh[lab, tt, pp] = 1.0
+    fd, ld = torch.from_numpy(feats).to(dev), torch.from_numpy(oh).to(dev)
+    eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=5, topk=k)
+    got = eng.predict(fd[:fi], fd[fi], ld[:, :fi], fi, 40, 5, 1.0, 8.0, 21.0, False).cpu().numpy()
+    over = eng.topk_overflows()
+    eng.close()
+    assert over == (0, 0, 0), over
+    cols = np.sort(rs.choice(HW, 400, replace=False))
+    want = vo.predict_columns(feats[:fi], feats[fi], oh[:, :fi], 8.0, 21.0, fi, 40, 5, 1.0, False, cols, topk=k).numpy()
+    tot = np.maximum(want.sum(0), 1e-30)
+    assert np.max(np.abs(got[:, cols] - want) / tot) <= 2e-2, np.max(np.abs(got[:, cols] - want) / tot)
