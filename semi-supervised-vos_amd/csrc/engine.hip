@@ -300,7 +300,8 @@ int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
             // several short segments; a segment start (target fragments, staging prologue, partial write) costs about as
             // much as `seg_cost` tile steps, so U is chosen to equalise  U + c  and  tail share + c * segments
             static const char* sc_env = getenv("VOSPROP_SEGCOST");
-            const double seg_cost = sc_env ? atof(sc_env) : 9.0;   // measured (r02 wall-clock stamps): ~6 us + the extras' lost lockstep
+            const double seg_cost = sc_env ? atof(sc_env) : 18.0;   // measured: a segment start costs ~12 us = ~17 steps of prop_mask_kernel
+                                                                    // (profiles/r04_segcost.txt: 480p 184.7 us at 9, 176.2 at 17, 176.1 at 21, 181.0 at 26)
             int U = RX;
             double best = 1e30;
             for (int u = 1; u <= RX; ++u) {

@@ -143,8 +143,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
 
     const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
     __syncthreads();      // s_off
+    Segment sg_next = A.segs[seg0 < seg1 ? seg0 : 0];
     for (int si = seg0; si < seg1; ++si) {
-        const Segment sg = A.segs[si];
+        const Segment sg = sg_next;
+        if (si + 1 < seg1) sg_next = A.segs[si + 1];      // the next record flies under this segment (one memory latency off its start)
         const int tt = __builtin_amdgcn_readfirstlane(sg.tt);
         const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);
         const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
@@ -179,6 +181,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
                 kq[sgm][cb] = A.tc_kq[(size_t)sgm * A.HWp + tq];
             }
 
+        // "tile -1" takes its labels from the last slot: zero them (0 x NaN)
+        if (tid_l < kMaskLab / 16) *(f32x4*)(smem + (kMaskRing - 1) * kMaskSlot + kMaskOffLab + tid_l * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ---- tiles 0 .. kMaskAhead-1 -> slots 0 .. kMaskAhead-1, issued BEFORE the control table is built (their source offsets are
+        // computed here directly): the table's arithmetic and its barrier then run under the memory latency of these pieces and
+        // of the target fragments
+#pragma unroll
+        for (int i = 0; i < kMaskAhead; ++i) {
+            const int r = r_lo + (i < n_steps - 1 ? i : n_steps - 1);
+            const int tile = r / N, n = r - tile * N;
+            const unsigned ea = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_off[n] + (unsigned)tile * (unsigned)kGlbFeat));
+            const unsigned el = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_off[kMaxRef + n] + (unsigned)tile * (unsigned)kMaskLab));
+            const unsigned eb = third_col == 0 ? ea : third_col == 1 ? (unsigned)tile * (unsigned)kLdsCoord : el;
+            const unsigned lds = smem_base + (unsigned)i * kMaskSlot;
+            glds16s2(src_a, ea, feat_base, lds, (unsigned)wave * 1024);
+            glds16s2(src_b, ea, feat_base, lds, ((unsigned)wave + 8) * 1024);
+            if (role_a) glds16s2(src_3, eb, third_base, lds, lds3_off);
+        }
+
         // ---- control table of the segment -> LDS (prop_mask.h has the entry format)
         for (int p0 = tid_l; p0 < n_steps + kMaskTabBlock + kMaskAhead; p0 += kWaves * 64) {
             const int p = p0 < n_steps - 1 ? p0 : n_steps - 1;
@@ -202,23 +223,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
         const unsigned tab_a = s_tab[lane_l * (kMaskTabEntry / 4)];
         const unsigned tab_b = s_tab[lane_l * (kMaskTabEntry / 4) + tab_col / 4];
 
-        // "tile -1" takes its labels from the last slot: zero them (0 x NaN)
-        if (tid_l < kMaskLab / 16) *(f32x4*)(smem + (kMaskRing - 1) * kMaskSlot + kMaskOffLab + tid_l * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // ---- tiles 0 .. kMaskAhead-1 -> slots 0 .. kMaskAhead-1
-#pragma unroll
-        for (int i = 0; i < kMaskAhead; ++i) {
-            const unsigned ea = (unsigned)__builtin_amdgcn_readlane((int)tab_a, i) & ~15u;
-            const unsigned eb = (unsigned)__builtin_amdgcn_readlane((int)tab_b, i);
-            const unsigned lds = smem_base + (unsigned)i * kMaskSlot;
-            glds16s2(src_a, ea, feat_base, lds, (unsigned)wave * 1024);
-            glds16s2(src_b, ea, feat_base, lds, ((unsigned)wave + 8) * 1024);
-            if (role_a) glds16s2(src_3, eb, third_base, lds, lds3_off);
-        }
-
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(Braw[i]));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (target fragments, constants and the first tiles' pieces)
         // c folded into the target side: T' = bf16(c T) (f16 features are converted on the way, one rounding); Bq = [cb][ks] x 4
         u32x16 Bq0, Bq1, Bq2, Bq3;
 #define VOSPROP_MASK_SET(idx, val)                          \
