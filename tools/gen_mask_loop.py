@@ -69,7 +69,7 @@ V_A = 192               # v[192:223] A[i] = 192 + 4 i
 V_PK = (224, 232)       # pk of even / odd tiles: + 4 cb + 2 rb + (i >> 1)
 V_LAB = 240             # v[240:243]
 V_CA = 248              # v[248:255] CA[rb] = 248 + 4 rb
-TEMPS = [172, 173, 174, 175, 244, 245, 246, 247, 248, 249, 250, 251, 252, 253, 254, 255, 46, 47, 30, 31]
+TEMPS = [248, 249, 250, 251, 252, 253, 254, 255, 46, 47, 30, 31]      # free at step boundaries (the coordinate fragments, spare CTL / AUX slots)
 # scalar registers of the statement (clobbers)
 S_Q, S_PHASE, S_CNT, S_IDX, S_TBASE, S_CENT, S_TMP, S_TMP2 = 70, 71, 72, 73, 74, 75, 76, 77
 S_HMASK = 78            # s[78:79] lanes 16-31 (k block 1: they hold K channels 8-15 of the prior MFMA's B operand)
@@ -588,7 +588,8 @@ def render(opts):
     out.append(f'#define VOSPROP_MASK_TAB_ENTRY {TAB_ENTRY}')
     out.append(f'#define VOSPROP_MASK_TAB_BLOCK {TAB_BLOCK}')
     out.append(f"#define VOSPROP_MASK_AHEAD {opts.get('ahead', AHEAD)}")
-    clob = [f'v{i}' for i in list(range(V_Q, V_Q + 8)) + list(range(V_LM, V_LM + 16)) + list(range(V_A, V_A + 32)) + list(range(V_LAB + 4, V_LAB + 16))]
+    # (v172-175 and v244-247 are NOT touched: hipcc keeps its own values there across the statement instead of in scratch)
+    clob = [f'v{i}' for i in list(range(V_Q, V_Q + 4)) + list(range(V_LM, V_LM + 16)) + list(range(V_A, V_A + 32)) + list(range(V_CA, V_CA + 8))]
     clob += [f's{i}' for i in range(S_Q, S_BC + 2)]
     out.append('#define VOSPROP_MASK_CLOBBERS ' + ', '.join(f'"{c}"' for c in clob) + ', "vcc", "scc", "memory"')
     # ONE statement per segment holds both roles and the rare paths: %[role] != 0 takes the second stream
