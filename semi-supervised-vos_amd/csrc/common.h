@@ -113,6 +113,7 @@ struct PropArgs {
     // prop_mask_kernel (prop_mask.h): target-side constants of the prior MFMA, built once per engine (engine.hip build_target_consts)
     const void* tc_b;           // [2 sigma][HWp][2 k halves] bf16x8: B fragment of the prior MFMA with c folded in and the 3-way split of -g Q_t c
     const float* tc_kq;         // [2 sigma][HWp] g Q_t c
+    unsigned long long* dbg;    // debug hook only (vosprop_debug_mask_stamps): [grid][8] wall-clock stamps of workgroup phases, else nullptr
 };
 
 }  // namespace vosprop

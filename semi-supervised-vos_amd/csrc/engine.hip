@@ -300,7 +300,7 @@ int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
             // several short segments; a segment start (target fragments, staging prologue, partial write) costs about as
             // much as `seg_cost` tile steps, so U is chosen to equalise  U + c  and  tail share + c * segments
             static const char* sc_env = getenv("VOSPROP_SEGCOST");
-            const double seg_cost = sc_env ? atof(sc_env) : 18.0;   // measured: a segment start costs ~12 us = ~17 steps of prop_mask_kernel
+            const double seg_cost = sc_env ? atof(sc_env) : 16.0;   // measured: a segment start costs ~12.8 us = ~15 steps of prop_mask_kernel
                                                                     // (profiles/r04_segcost.txt: 480p 184.7 us at 9, 176.2 at 17, 176.1 at 21, 181.0 at 26)
             int U = RX;
             double best = 1e30;
@@ -1271,6 +1271,26 @@ int vosprop_time_last_propagation(vosprop_ctx* ctx, int iters, void* stream, dou
     HIP_TRY(ctx, hipGetLastError());
     *mean_us = (double)ms * 1000.0 / iters;
     return VOSPROP_OK;
+}
+
+// Debug hook (not part of include/vosprop.h; tools/mask_stamps.py): re-run the last mask-only propagation with wall-clock stamps of
+// every workgroup's phases (prop_mask.h VOSPROP_MASK_STAMP; 100 MHz s_memrealtime).  out_host: [grid][8] u64.  Returns the grid size.
+int vosprop_debug_mask_stamps(vosprop_ctx* ctx, unsigned long long* out_host, int max_words) {
+    if (!ctx || !ctx->last.valid || !ctx->last.no_l) return VOSPROP_E_STATE;
+    LastProp lp = ctx->last;
+    const size_t n = (size_t)lp.grid * 8;
+    if ((size_t)max_words < n) return VOSPROP_E_INVALID;
+    unsigned long long* d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d, n * 8));
+    HIP_TRY(ctx, hipMemset(d, 0, n * 8));
+    for (int i = 0; i < 3; ++i) launch_prop(ctx, ctx->last, nullptr);      // warm, back to back like the timing loop
+    lp.args.dbg = d;
+    launch_prop(ctx, lp, nullptr);
+    launch_prop(ctx, ctx->last, nullptr);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemcpy(out_host, d, n * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return lp.grid;
 }
 
 // Debug hook (not part of include/vosprop.h; tools/dbg_mask.py): re-run the last DENSE label-mode propagation with prop_mask_kernel

@@ -83,6 +83,16 @@ constexpr int kMaskLab = 1024;                               // bytes of one til
 constexpr int kMaskMaxClasses = 16;
 static_assert(kMaskOffCoord == kTileR * kMaskRowB && kMaskOffLab == kMaskOffCoord + kLdsCoord && kMaskSlot == kMaskOffLab + kMaskLab, "slot layout");
 
+// debug hook (tools/mask_stamps.py): 100 MHz wall clock of a workgroup's phases; a null A.dbg costs one scalar compare per stamp
+#define VOSPROP_MASK_STAMP(k)                                                                        \
+    do {                                                                                             \
+        if (A.dbg && tid == 0) {                                                                     \
+            unsigned long long t_;                                                                   \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            if ((k) < 2 || si == seg0 || (k) >= 6) A.dbg[(size_t)blockIdx.x * 8 + (k)] = t_;       \
+        }                                                                                            \
+    } while (0)
+
 __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArgs A) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[kMaskRing * kMaskSlot];
     __shared__ unsigned s_off[2 * kMaxRef];      // per sampled frame: byte offset of its slot in the feature ring / lab16 ring
@@ -142,8 +152,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
     const unsigned tab_col = third_col == 0 ? 12u : third_col == 1 ? 4u : 8u;      // this wave's TB column inside an entry
 
     const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
+    Segment sg_next = A.segs[seg0 < seg1 ? seg0 : 0];      // (issued before the barrier below: it flies beside the slot table's load)
+    {
+        const int si = seg0;
+        VOSPROP_MASK_STAMP(0);      // 0: kernel entry (after the kernel arguments and the segment range)
+    }
     __syncthreads();      // s_off
-    Segment sg_next = A.segs[seg0 < seg1 ? seg0 : 0];
     for (int si = seg0; si < seg1; ++si) {
         const Segment sg = sg_next;
         if (si + 1 < seg1) sg_next = A.segs[si + 1];      // the next record flies under this segment (one memory latency off its start)
@@ -152,6 +166,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
         const int n_steps = __builtin_amdgcn_readfirstlane(sg.n_steps);
         const int part_slot = __builtin_amdgcn_readfirstlane(sg.slot);
 
+        VOSPROP_MASK_STAMP(1);      // 1: the first segment's record is here
         int tid_l = tid;
         asm volatile("" : "+v"(tid_l));
         const int lane_l = tid_l & 63, j16 = tid_l & 15, kb = (tid_l >> 4) & 3;
@@ -225,7 +240,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
 
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(Braw[i]));
+        VOSPROP_MASK_STAMP(2);      // 2: everything of the prologue is issued, the control table is built
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (target fragments, constants and the first tiles' pieces)
+        VOSPROP_MASK_STAMP(3);      // 3: ... and has landed
         // c folded into the target side: T' = bf16(c T) (f16 features are converted on the way, one rounding); Bq = [cb][ks] x 4
         u32x16 Bq0, Bq1, Bq2, Bq3;
 #define VOSPROP_MASK_SET(idx, val)                          \
@@ -292,6 +309,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
         const int n0 = r_lo - (r_lo / N) * N;
         const unsigned sp0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((A.sparse_mask >> n0) & 1ull));
 
+        VOSPROP_MASK_STAMP(4);      // 4: target fragments scaled, loop inputs assembled
         // ---- the tile loop, its control and its rare paths: ONE statement per segment ----
         f32x16 S0, S1;
         f32x8 Y;
@@ -308,6 +326,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
                            [ldsa] "s"(ldsa), [lds3] "s"(lds3), [role] "s"(role_b), [tab] "s"(tab_base), [sp0] "s"(sp0)
                          : VOSPROP_MASK_CLOBBERS);
         }
+        VOSPROP_MASK_STAMP(5);      // 5: the first segment's tile loop is done
         const bool centred = n_steps >= 2;      // the first tile went through the rescale path (boundary 2)
 
         // ---- the segment's last two tiles have no chain to hide under ----
@@ -367,6 +386,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
                 if (cls < A.d) part[(size_t)(2 + cls) * kBT] = Yc[cb][i];
             }
         }
+        VOSPROP_MASK_STAMP(6);      // 6: the (last) segment's partial is stored
+    }
+    {
+        const int si = seg0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VOSPROP_MASK_STAMP(7);      // 7: kernel exit
     }
 }
 

@@ -15,7 +15,7 @@ import torch.utils.data
 from .config import Config
 from .datasets import InferenceDataset, list_videos
 from .io_pipeline import ShmFrameLoader, default_io_workers, make_loader
-from .inference_utils import (inference_2_scale, inference_3_scale, inference_hor_flip, inference_multimodel,
+from .inference_utils import (EncoderNotReproducible, inference_2_scale, inference_3_scale, inference_hor_flip, inference_multimodel,
                               inference_single, inference_ver_flip)
 from .sharding import shard_for_rank
 from .utils import load_model
@@ -100,6 +100,9 @@ _MIOPEN_NONDETERMINISTIC_SOLVERS = ('MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC
 _SPLIT_K_PIXELS = 131072
 
 
+_SET_BY_US = set()      # MIOpen environment switches THIS module set (and may therefore remove again)
+
+
 def set_deterministic(on=True, pixels_per_batch=None):
     """Process-wide reproducible mode of the encoder (measured with tools/determinism_probe.py).  Call it
     before the first convolution of the process (the CLI does, first thing).  pixels_per_batch: encoder batch x ceil(H/8) x
@@ -117,10 +120,14 @@ def set_deterministic(on=True, pixels_per_batch=None):
     from . import _native
     small = pixels_per_batch is None or pixels_per_batch < _SPLIT_K_PIXELS
     for name in _MIOPEN_NONDETERMINISTIC_SOLVERS:
+        if name in os.environ and name not in _SET_BY_US:
+            continue                        # the user's own setting of a MIOpen switch is never touched
         if on and small:
             os.environ[name] = '0'
-        else:
+            _SET_BY_US.add(name)
+        elif name in _SET_BY_US:
             os.environ.pop(name, None)
+            _SET_BY_US.discard(name)
     if on:
         torch.backends.cudnn.benchmark = False
     _native.lib().vosprop_set_deterministic(1 if on else 0)
@@ -193,7 +200,10 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
             with Image.open(first[0]) as im0:
                 w0, h0 = im0.size
             det_shape = (max(1, encoder_batch), 3, h0, w0)
-        set_deterministic(True, None if det_shape is None else det_shape[0] * -(-h0 // 8) * -(-w0 // 8))
+        # strategies with scaled branches (2-scale, hor-2-scale, 3-scale) encode other sizes as well: unknown = the safe choice
+        # (solver family off); every distinct input shape is verified bitwise on its first batch anyway (encoded_branches)
+        same_size = inference_strategy in ('single', 'multimodel', 'hor-flip', 'vert-flip')
+        set_deterministic(True, None if (det_shape is None or not same_size) else det_shape[0] * -(-h0 // 8) * -(-w0 // 8))
         miopen_find = False        # a timed solver search is a race between solvers: its winner can differ from process to process
     if Config.DEVICE.type != device:
         Config.DEVICE = torch.device(device)
@@ -250,6 +260,19 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
                 temperature, probability_propagation)
         opts = dict(encoder_dtype=dtype, stats=stats, encoder_batch=encoder_batch, png_workers=png_workers,
                     precision={'bf16': 0, 'f32': 1}[propagation_precision], align_videos=deterministic)
+        try:
+            _run_strategy(inference_strategy, net, additional, head, opts, disable, reduction, scale)
+        except EncoderNotReproducible as e:      # --deterministic: a batch of some input shape did not repeat bit for bit
+            raise click.ClickException(str(e))
+    if hasattr(loader, 'close'):
+        loader.close()
+    stats['shard'] = list(shard)
+    print(json.dumps({'vosprop_stats': stats}))
+
+
+def _run_strategy(inference_strategy, net, additional, head, opts, disable, reduction, scale):
+    """The reference's dispatch over its strategies (src/inference.py:84-103)."""
+    if True:
         if inference_strategy == 'single':
             inference_single(net, *head, disable, **opts)
         elif inference_strategy == 'hor-flip':
@@ -264,7 +287,3 @@ def inference_command_impl(ref_num, data, resume, model, temperature, frame_rang
             inference_2_scale(net, *head, scale, reduction, True, disable, **opts)
         elif inference_strategy == '3-scale':
             inference_3_scale(net, *head, scale, disable, **opts)
-    if hasattr(loader, 'close'):
-        loader.close()
-    stats['shard'] = list(shard)
-    print(json.dumps({'vosprop_stats': stats}))

@@ -23,6 +23,10 @@ def _read_annotation(path):
     return np.asarray(ann), ann.getpalette(), ann
 
 
+class EncoderNotReproducible(RuntimeError):
+    """--deterministic: an encoder batch did not repeat bit for bit (inference.py turns it into a click.ClickException)."""
+
+
 def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None, align_videos=False):
     """Encoder look-ahead for every strategy: yields ([features (1,C,H_d,W_d) per branch], video_name) in loader order, but
     runs each encoder on `batch` consecutive frames at a time - the features do not depend on the propagated labels (only the
@@ -34,8 +38,11 @@ def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None, 
     3-scale strategy's (reference inference_utils.py:523-526).  align_videos (`--deterministic`): a batch also ends where the video
     changes, so the position of a frame inside its encoder batch depends on its index in its video only - whichever other videos
     the process was given (a library GEMM may split tiles differently along the batch; measured position-independent on this
-    stack, but nothing promises it)."""
+    stack, but nothing promises it).  In that mode the FIRST batch of every distinct (branch, input shape) is also encoded twice
+    more and compared bitwise (`EncoderNotReproducible` on a mismatch): the reproducibility of the library's kernels depends on the
+    problem size, and scaled branches or a dataset with mixed frame sizes reach sizes the start-up check never saw."""
     nb = len(models)
+    verified = set()
     pend = [[] for _ in range(nb)]
     names = []
     copy_stream = [torch.cuda.Stream(device)]
@@ -67,7 +74,17 @@ def encoded_branches(models, loader, device, encoder_dtype, batch, resize=None, 
             if encoder_dtype is not None:
                 x = x.to(encoder_dtype)
             with torch.no_grad():
-                f = models[b](x.contiguous(memory_format=torch.channels_last))
+                xc = x.contiguous(memory_format=torch.channels_last)
+                f = models[b](xc)
+                key = (b, tuple(xc.shape), xc.dtype)
+                if align_videos and torch.device(device).type == 'cuda' and key not in verified:
+                    ref = f.clone()
+                    if not (torch.equal(models[b](xc), ref) and torch.equal(models[b](xc), ref)):
+                        raise EncoderNotReproducible(f'--deterministic: the encoder is NOT bit-reproducible for input {tuple(xc.shape)} '
+                                                     f'({xc.dtype}) on this software stack (a library kernel accumulates with atomics); '
+                                                     'see DESIGN.md section 7.1 / tools/determinism_probe.py')
+                    verified.add(key)
+                    f = ref
             if any(models[c] is models[b] for c in range(b + 1, nb)):
                 f = f.clone()       # a graph-replaying encoder reuses its output buffer: the next branch would overwrite it
             feats.append(f)

@@ -418,7 +418,7 @@ def test_work_plan_covers_every_unit_once(vos, TT, NT):
         x = b % 8
         assert ns > 0 and x * NT // 8 <= r_lo and r_lo + ns <= (x + 1) * NT // 8
         cover[tt, r_lo:r_lo + ns] += 1
-        load[b] += ns + 18      # the lockstep map prices a segment start at 18 tile steps (VOSPROP_SEGCOST; measured)
+        load[b] += ns + 16      # the lockstep map prices a segment start at 16 tile steps (VOSPROP_SEGCOST; measured)
     assert cover.min() == 1 and cover.max() == 1
     if TT * NT >= 8 * 32 * 8:
         per_xcd = collections.defaultdict(list)

@@ -112,6 +112,7 @@ class Stream:
         self.role_pieces = role_pieces
         self.barrier_gap = barrier_gap
         self.opts = opts
+        self.outlined = []      # rare blocks laid out behind the loop (text lines): the common path falls through
 
     def emit(self, text, kind='s', reads=(), writes=(), nops=1):
         self.ins.append(Ins(text, kind, reads, writes, nops))
@@ -251,10 +252,6 @@ def gen_step(st, k, tag):
             if npieces == 3:
                 e(f's_add_u32 s{S_BC}, %[tb_lo], s{S_OFFB}', 's')
                 e(f's_addc_u32 s{S_BC + 1}, %[tb_hi], 0', 's')
-        if g == 3:
-            for r2 in range(2):
-                reg, off = coord_addr(nxt, r2)
-                st.ds_read(f'CA{r2}', V_CA + 4 * r2, 4, reg, off)
         if g in dma_gaps:
             piece_dma(dma_gaps.index(g))
         for r in exp_rows.get(g, []):
@@ -266,22 +263,26 @@ def gen_step(st, k, tag):
             vcvt(p, (2 * p) % 4, (2 * p + 1) % 4)
         if g == 9:
             e(f'v_cmp_lt_f32_e32 vcc, 0x{float_bits(ALARM):08x}, v{V_MX}', 'valu', reads=[V_MX])
-        if g == 10:
-            # tile q+1 opens a pixel tile or a sigma class: its prior tile LM[rb][cb] = coordinates x target-side constants
-            st.wait_for('CA1')
-            if 'no_lm' not in ab:
-                e(f's_bitcmp1_b32 s{S_RAWA}, 0', 's')
-                e(f's_cbranch_scc0 LW{k}_{tag}', 'branch')
-                e(f's_bitcmp1_b32 s{S_RAWA}, 1', 's')
-                e(f's_cbranch_scc1 LV{k}_{tag}', 'branch')
-                for sg in range(2):
-                    if sg == 1:
-                        e(f's_branch LW{k}_{tag}', 'branch')
-                        st.label(f'LV{k}_{tag}')
-                    for r2 in range(2):
-                        for cb in range(2):
-                            mfma(s_reg(V_LM, r2, cb), V_CA + 4 * r2, V_CB + 8 * sg + 4 * cb, None)
-                st.label(f'LW{k}_{tag}')
+        if g == 10 and 'no_lm' not in ab:
+            # tile q+1 opens a pixel tile or a sigma class (2 steps in 9 at N = 9): its prior tile LM[rb][cb] = coordinates x
+            # target-side constants, four MFMAs - OUT OF LINE behind the loop, so that the common path is one untaken branch.  The
+            # block reads the two coordinate fragments itself and drains the LDS queue (lgkmcnt(0): the queue model is untouched)
+            e(f's_bitcmp1_b32 s{S_RAWA}, 0', 's')
+            e(f's_cbranch_scc1 LM{k}_{tag}', 'branch')
+            st.label(f'LW{k}_{tag}')
+            blk = [f'LM{k}_{tag}:']
+            for r2 in range(2):
+                reg, off = coord_addr(nxt, r2)
+                blk.append(f'ds_read_b128 {vr(V_CA + 4 * r2, 4)}, v{reg} offset:{off}')
+            blk += ['s_waitcnt lgkmcnt(0)', f's_bitcmp1_b32 s{S_RAWA}, 1', f's_cbranch_scc1 LV{k}_{tag}']
+            for sg in range(2):
+                if sg == 1:
+                    blk += [f's_branch LW{k}_{tag}', f'LV{k}_{tag}:']
+                for r2 in range(2):
+                    for cb in range(2):
+                        blk.append(f'v_mfma_f32_16x16x32_bf16 {vr(s_reg(V_LM, r2, cb), 4)}, {vr(V_CA + 4 * r2, 4)}, {vr(V_CB + 8 * sg + 4 * cb, 4)}, 0')
+            blk.append(f's_branch LW{k}_{tag}')
+            st.outlined.append(blk)
         if g == 12 and 'no_lab' not in ab:
             reg, off = lane_addr(prv, OFF_LAB)
             st.ds_read('LAB', V_LAB, 4, reg, off)
@@ -376,6 +377,7 @@ def gen_role(tag, npieces, opts):
     for _ in range(2):
         start = len(st.ins)
         fifo_before = list(st.fifo)
+        st.outlined = []
         for k in range(NSLOT):
             gen_step(st, k, tag)
         st.emit(f's_branch L0_{tag}', 'branch')
@@ -477,7 +479,7 @@ def gen_role(tag, npieces, opts):
         f's_branch LCTL_{tag}',
         f'LDONE_{tag}:',
     ]
-    lines = head + [i.text for i in steady] + tail
+    lines = head + [i.text for i in steady] + [ln for blk in st.outlined for ln in blk] + tail
     return lines, steady
 
 
