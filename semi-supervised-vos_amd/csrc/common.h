@@ -81,6 +81,8 @@ struct PropArgs {
     unsigned long long sparse_mask;   // bit n set: frame n uses sigma2 (the "interval" frames)
     const Segment* segs;        // segment table of this launch
     const int* seg_off;         // [grid + 1] segments of workgroup b: segs[seg_off[b]] .. segs[seg_off[b + 1] - 1]
+    const Segment* seg_first;   // [grid] a copy of segs[seg_off[b]] (zeros for a workgroup without work): the first record loads beside
+                                // the range, not behind it (one dependent round trip off every launch)
     int target_slot;
     const bf16_t* target_feat;  // dense bf16 kernel: the target frame's features [target_rows][kC] - its ring slot, or the caller's own
     int target_rows;            // channels-last bf16 buffer (HW rows) when the ring copy rides in combine_kernel (engine.hip vosprop_step)

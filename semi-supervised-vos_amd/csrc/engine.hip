@@ -67,6 +67,7 @@ struct Plan {
     int* d_list = nullptr;    // slot indices, CSR by target tile
     Segment* d_segs = nullptr;
     int* d_seg_off = nullptr; // [grid + 1]
+    Segment* d_first = nullptr; // [grid] each workgroup's first record again (PropArgs::seg_first)
 };
 
 }  // namespace
@@ -311,6 +312,24 @@ int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
                 const double cost = std::max(u + seg_cost, share + seg_cost * nseg);
                 if (cost < best) { best = cost; U = u; }
             }
+            // Small maps (few steps per workgroup): giving every leftover tile a WHOLE number of workgroups (1 + E / rem, equal pieces,
+            // one segment each) beats the shared tail, whose second segment start is not amortised there (240p: 48 of 256
+            // workgroups ran two segments of ~6 steps and finished 8 us behind the rest)
+            {
+                const int pieces_min = 1 + E / rem;
+                const double cost_whole = (double)((RX + pieces_min - 1) / pieces_min) + seg_cost;
+                if (cost_whole < best) {
+                    int wg = 0;
+                    for (int t = 0; t < rem; ++t) {
+                        const int pieces = 1 + E / rem + (t < E % rem ? 1 : 0);
+                        for (int pc = 0; pc < pieces; ++pc, ++wg) {
+                            const int lo = (int)((long long)RX * pc / pieces), hi = (int)((long long)RX * (pc + 1) / pieces);
+                            add(x, wg, k * I + t, r0 + lo, hi - lo);
+                        }
+                    }
+                    continue;
+                }
+            }
             for (int i = 0; i < rem; ++i) add(x, i, k * I + i, r0, U);   // primaries: head of their own tile, in lockstep
             const int tail = RX - U;                                      // per leftover tile, walked by the extras
             const long long Q = (long long)rem * tail;
@@ -367,6 +386,11 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
     HIP_TRY(ctx, hipMalloc((void**)&p.d_list, (flat.size() + 1) * sizeof(int)));
     HIP_TRY(ctx, hipMalloc((void**)&p.d_segs, (segs.size() + 1) * sizeof(Segment)));
     HIP_TRY(ctx, hipMalloc((void**)&p.d_seg_off, seg_off.size() * sizeof(int)));
+    std::vector<Segment> first((size_t)p.grid, Segment{0, 0, 0, 0});
+    for (int b = 0; b < p.grid; ++b)
+        if (seg_off[(size_t)b] < seg_off[(size_t)b + 1]) first[(size_t)b] = segs[(size_t)seg_off[(size_t)b]];
+    HIP_TRY(ctx, hipMalloc((void**)&p.d_first, first.size() * sizeof(Segment)));
+    HIP_TRY(ctx, hipMemcpy(p.d_first, first.data(), first.size() * sizeof(Segment), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(p.d_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(p.d_list, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(p.d_segs, segs.data(), segs.size() * sizeof(Segment), hipMemcpyHostToDevice));
@@ -548,6 +572,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     if (rc) return rc;
     a.segs = plan->d_segs;
     a.seg_off = plan->d_seg_off;
+    a.seg_first = plan->d_first;
     a.c = (float)((double)temperature * 1.4426950408889634);
     a.g1 = 1.0 / ((double)sigma1 * sigma1 * temperature);
     a.g2 = 1.0 / ((double)sigma2 * sigma2 * temperature);
@@ -994,6 +1019,7 @@ void vosprop_destroy(vosprop_ctx* ctx) {
         if (p.d_list) (void)hipFree(p.d_list);
         if (p.d_segs) (void)hipFree(p.d_segs);
         if (p.d_seg_off) (void)hipFree(p.d_seg_off);
+        if (p.d_first) (void)hipFree(p.d_first);
     }
     if (ctx->pred_buf) (void)hipFree(ctx->pred_buf);
     if (ctx->cls_tmp) (void)hipFree(ctx->cls_tmp);

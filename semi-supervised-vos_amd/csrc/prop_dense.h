@@ -177,6 +177,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
 
     // TK 2 has no segment table: workgroup b is share (b % tk_chunks) of target tile (b / tk_chunks)
     const int seg0 = TK == 2 ? 0 : A.seg_off[blockIdx.x], seg1 = TK == 2 ? 1 : A.seg_off[blockIdx.x + 1];
+    Segment sg_first = Segment{0, 0, 0, 0};      // (a copy of segs[seg0]: it loads beside the range, not behind it)
+    if (TK != 2) sg_first = A.seg_first[blockIdx.x];
     if (TK == 1) {      // pass 1 also clears the bitmaps topk_select2_kernel will mark (it runs after this kernel on the stream)
         for (int i = blockIdx.x * (kWaves * 64) + tid; i < A.tk_bitmap_words; i += gridDim.x * (kWaves * 64)) A.tk_bitmap[i] = 0u;
     }
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_dense_kernel(const PropAr
             sg.r_lo = 0;
             sg.n_steps = hi - lo < kTkListCap ? hi - lo : kTkListCap;
         } else {
-            sg = A.segs[si];
+            sg = si == seg0 ? sg_first : A.segs[si];
         }
         const int tt = __builtin_amdgcn_readfirstlane(sg.tt);
         const int r_lo = __builtin_amdgcn_readfirstlane(sg.r_lo);

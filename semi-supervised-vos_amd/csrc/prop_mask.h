@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
     const unsigned tab_col = third_col == 0 ? 12u : third_col == 1 ? 4u : 8u;      // this wave's TB column inside an entry
 
     const int seg0 = A.seg_off[blockIdx.x], seg1 = A.seg_off[blockIdx.x + 1];
-    Segment sg_next = A.segs[seg0 < seg1 ? seg0 : 0];      // (issued before the barrier below: it flies beside the slot table's load)
+    Segment sg_next = A.seg_first[blockIdx.x];      // (a copy of segs[seg0]: it loads beside the range, not behind it)
     {
         const int si = seg0;
         VOSPROP_MASK_STAMP(0);      // 0: kernel entry (after the kernel arguments and the segment range)

@@ -4,7 +4,6 @@ features ~ N(0, 0.25^2) rounded to bf16 (logits ~ N(0,1)), uniform one-hot label
 branches are live.  Prints the mean kernel time from HIP events (vosprop_time_last_propagation).
 Used under rocprofv3 for the PMC passes."""
 import argparse
-import os
 import importlib
 import json
 import sys
@@ -58,40 +57,6 @@ def main():
                       'algorithmic_gb_per_s': st['bytes'] / us / 1e3,
                       'workgroups': st['workgroups'], 'tiles_per_wg': st['tiles_per_wg'], 'n_ref': st['n_ref'],
                       'hw': st['hw'], 'checksum': float(out.sum())}))
-    L = vos._native.lib()
-    if hasattr(L, 'vosprop_debug_stamps'):     # -DVOSPROP_STAMP diagnostic build
-        import ctypes
-        import numpy as np
-        NS = 16
-        n = st['workgroups'] * 8 * NS
-        buf = np.zeros(n, dtype=np.uint64)
-        L.vosprop_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-        got = L.vosprop_debug_stamps(eng._ctx, buf.ctypes.data_as(ctypes.c_void_p), n)
-        assert got == n, got
-        a = buf.reshape(-1, 8, NS).astype(np.float64) / st['tiles_per_wg']
-        names = ['loop', 'ld-issue', 'mfma', 'bar1', 'prefetch', 'max', 'exp', 'labmfma', 'stwrite', 'bar2']
-        if not os.environ.get('VOSPROP_DENSE_TWO_BURST') and not args.topk:
-            names = ['head', 'gaps0-7', 'gaps8-15', 'check+labmfma', 'tail+prior', 'dmawait', 'barrier', 'seg-prologue', 'seg-close', '-', 'segments', '-', 'pro:record', 'pro:issue', 'pro:wait']
-        print('stamps: cycles per tile')
-        for g, sl in (('A (waves 0-3)', slice(0, 4)), ('B (waves 4-7)', slice(4, 8))):
-            m = a[:, sl].mean((0, 1))
-            print(f'  group {g}: ' + ' '.join(f'{nm}={v:.0f}' for nm, v in zip(names, m)) + f'  total={m.sum():.0f}')
-        raw = buf.reshape(-1, 8, NS)
-        if raw[:, :, 9].any():     # dense kernel: 100 MHz wall clock at the first and after the last instruction of every wave
-            t0 = raw[:, :, 9].astype(np.int64)
-            t1 = raw[:, :, 11].astype(np.int64)
-            z = t0.min()
-            st_us, en_us = (t0 - z) / 100.0, (t1 - z) / 100.0
-            nseg = raw[:, 0, 10]
-            print('  wall clock (us after the first wave started): wave start mean=%.1f max=%.1f; wave end min=%.1f mean=%.1f max=%.1f'
-                  % (st_us.mean(), st_us.max(), en_us.min(), en_us.mean(), en_us.max()))
-            for k in sorted(set(nseg.tolist())):
-                sel = nseg == k
-                print('    workgroups with %d segment(s): %d, end mean=%.1f max=%.1f us' % (k, sel.sum(), en_us[sel].mean(), en_us[sel].max()))
-        tot = buf.reshape(-1, 8, NS).astype(np.float64)
-        print('  per wave, whole kernel (cycles): stamped total mean=%.0f max=%.0f; segment prologues mean=%.0f max=%.0f; segments mean=%.2f max=%.0f'
-              % (tot[:, :, :9].sum(2).mean(), tot[:, :, :9].sum(2).max(), tot[:, :, 7].mean(), tot[:, :, 7].max(),
-                 tot[:, :, 10].mean(), tot[:, :, 10].max()))
     eng.close()
 
 
