@@ -43,7 +43,8 @@ struct LastProp {
     int grid = 0;
     bool prob = false, lab_lo = false;
     bool materialise = false;
-    bool no_l = false;    // dense label mode, prediction not requested: prop_dense_kernel<..., NEED_L = false>
+    bool no_l = false;    // dense label mode, prediction not requested: prop_mask_kernel
+    int plan_last_active = 0;      // which plan of (NT) the launch walks (Plan::last_active)
     int topk = 0;
     // top-k (prop_dense.h TK 1 / 2): pass 1 = `args` with the list partials, then topk_select2_kernel, then pass 2 on its own grid
     int tk_ks = 0;                 // list slots per lane: ceil(k / 8) * 8
@@ -58,6 +59,7 @@ struct LastProp {
 // Device copy of the partial-slot lists of one work decomposition (depends only on TT, NT).
 struct Plan {
     int NT = -1;
+    int last_active = 0;      // build_segments' last_active this plan was built for (0: every step costs the same)
     int grid = 0;             // workgroups = 8 * wg_per_xcd
     int wg_per_xcd = 0;
     int steps_per_wg = 0;     // reference tiles the busiest workgroup walks (stats)
@@ -279,7 +281,10 @@ int ensure_part(vosprop_ctx* ctx, size_t bytes) {
 // partial slots that will hold it.  Cached per NT; built on first use (a few microseconds of host work).
 // Pure host function: the segment lists of every workgroup (index b = i * 8 + x runs on XCD x) for TT target tiles and NT
 // reference tiles.  Returns the workgroups per XCD.
-int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
+// last_active (0 = not told): how many of the LAST target tile's 8 waves hold a column of the map.  prop_mask_kernel runs the others in
+// its staging-only form, and a workgroup on that tile then steps faster (480p, 1 active wave: 594 ns against 848 ns) - its primary
+// is given a longer head for the same finishing time.
+int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg, int last_active = 0) {
     long long per_xcd = ((long long)TT * NT + kXcd - 1) / kXcd;
     long long Iq = per_xcd / 4;   // at least ~4 tile steps per workgroup
     const int I = (int)(Iq < 1 ? 1 : (Iq > 32 ? 32 : Iq));
@@ -287,6 +292,7 @@ int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
     auto add = [&](int x, int i, int tt, int r_lo, int n) {
         if (n > 0) per_wg[(size_t)(i * kXcd + x)].push_back(Segment{tt, r_lo, n, 0});
     };
+    const double w_last = last_active > 0 && last_active < kWaves ? 0.66 + 0.34 * last_active / kWaves : 1.0;   // step time on the last tile
     for (int x = 0; x < kXcd; ++x) {
         const int r0 = (int)((long long)x * NT / kXcd), r1 = (int)((long long)(x + 1) * NT / kXcd);
         const int RX = r1 - r0;
@@ -297,18 +303,21 @@ int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
             for (int i = 0; i < I; ++i) add(x, i, j * I + i, r0, RX);
         if (rem > 0) {
             const int E = I - rem;                                        // extra workgroups (>= 1)
-            // head length U: the primaries walk U tiles in one segment, the E extras share rem * (RX - U) tail tiles in
-            // several short segments; a segment start (target fragments, staging prologue, partial write) costs about as
+            // head length U: the primaries walk U tiles in one segment (the last tile's primary U / w_last), the E extras share the
+            // tails in several short segments; a segment start (target fragments, staging prologue, partial write) costs about as
             // much as `seg_cost` tile steps, so U is chosen to equalise  U + c  and  tail share + c * segments
             static const char* sc_env = getenv("VOSPROP_SEGCOST");
             const double seg_cost = sc_env ? atof(sc_env) : 16.0;   // measured: a segment start costs ~12.8 us = ~15 steps of prop_mask_kernel
                                                                     // (profiles/r04_segcost.txt: 480p 184.7 us at 9, 176.2 at 17, 176.1 at 21, 181.0 at 26)
+            auto head_last = [&](int u) { const int ul = (int)(u / w_last); return ul < RX ? ul : RX; };
             int U = RX;
             double best = 1e30;
             for (int u = 1; u <= RX; ++u) {
-                const int tl = RX - u;
-                const double share = (double)rem * tl / E;
-                const double nseg = tl > 0 ? share / tl + 1.0 : 0.0;
+                const int tl = RX - u, tll = RX - head_last(u);
+                const double Q = (double)(rem - 1) * tl + tll;
+                const int ntails = (tl > 0 ? rem - 1 : 0) + (tll > 0 ? 1 : 0);
+                const double share = Q / E;
+                const double nseg = Q > 0 ? (double)ntails / E + 1.0 : 0.0;
                 const double cost = std::max(u + seg_cost, share + seg_cost * nseg);
                 if (cost < best) { best = cost; U = u; }
             }
@@ -330,17 +339,22 @@ int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
                     continue;
                 }
             }
-            for (int i = 0; i < rem; ++i) add(x, i, k * I + i, r0, U);   // primaries: head of their own tile, in lockstep
-            const int tail = RX - U;                                      // per leftover tile, walked by the extras
-            const long long Q = (long long)rem * tail;
-            for (int e = 0; e < E && tail > 0; ++e) {
+            std::vector<int> head((size_t)rem, U);
+            head[(size_t)rem - 1] = head_last(U);
+            for (int i = 0; i < rem; ++i) add(x, i, k * I + i, r0, head[(size_t)i]);   // primaries: head of their own tile, in lockstep
+            // the tails, end to end, walked by the extras: position q lies in tile t at offset q - pre[t]
+            std::vector<long long> pre((size_t)rem + 1, 0);
+            for (int t = 0; t < rem; ++t) pre[(size_t)t + 1] = pre[(size_t)t] + (RX - head[(size_t)t]);
+            const long long Q = pre[(size_t)rem];
+            int t = 0;
+            for (int e = 0; e < E && Q > 0; ++e) {
                 long long q = Q * e / E;
                 const long long q1 = Q * (e + 1) / E;
                 while (q < q1) {
-                    const int t = (int)(q / tail);
-                    long long qe = (long long)(t + 1) * tail;
+                    while (pre[(size_t)t + 1] <= q) ++t;
+                    long long qe = pre[(size_t)t + 1];
                     if (qe > q1) qe = q1;
-                    add(x, rem + e, k * I + t, r0 + U + (int)(q - (long long)t * tail), (int)(qe - q));
+                    add(x, rem + e, k * I + t, r0 + head[(size_t)t] + (int)(q - pre[(size_t)t]), (int)(qe - q));
                     q = qe;
                 }
             }
@@ -349,14 +363,15 @@ int build_segments(int TT, int NT, std::vector<std::vector<Segment>>& per_wg) {
     return I;
 }
 
-int get_plan(vosprop_ctx* ctx, int NT, const Plan** out) {
+int get_plan(vosprop_ctx* ctx, int NT, const Plan** out, int last_active = 0) {
     for (const Plan& p : ctx->plans)
-        if (p.NT == NT) { *out = &p; return VOSPROP_OK; }
+        if (p.NT == NT && p.last_active == last_active) { *out = &p; return VOSPROP_OK; }
     Plan p;
     p.NT = NT;
+    p.last_active = last_active;
     const int TT = ctx->TT;
     std::vector<std::vector<Segment>> per_wg;
-    p.wg_per_xcd = build_segments(TT, NT, per_wg);
+    p.wg_per_xcd = build_segments(TT, NT, per_wg, last_active);
     p.grid = kXcd * p.wg_per_xcd;
     // Partial slots are numbered so that the slots of one target tile are CONSECUTIVE: slot = off[tt] + (its rank among the tile's
     // segments).  The kernels that merge partials then need `off` only - the slot list is the identity and they do not load it (one
@@ -567,9 +582,16 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     a.Wd = ctx->cfg.feat_w;
     a.d = d;
     a.tiles_per_frame = ctx->tiles;
+    // the mask-only label-mode step is prop_mask_kernel (prop_mask.h) when its limits hold; its plan knows that the last target
+    // tile's waves beyond the map only stage (build_segments' last_active)
+    const bool mask_form = ctx->mask_only && !prob && !lab_lo && !topk && !f32 && ctx->cfg.materialise == 0 && d <= kMaskMaxClasses;
+    const int last_cols = ctx->HW - (ctx->TT - 1) * kBT;
+    const int last_active = (last_cols + kColsPerWave - 1) / kColsPerWave;
     const Plan* plan = nullptr;
-    int rc = get_plan(ctx, n_ref * ctx->tiles, &plan);
+    int rc = get_plan(ctx, n_ref * ctx->tiles, &plan, mask_form && last_active < kWaves ? last_active : 0);
+    if (!rc && mask_form && plan->steps_per_wg > kMaskMaxSteps) rc = get_plan(ctx, n_ref * ctx->tiles, &plan);   // -> prop_dense_kernel
     if (rc) return rc;
+    lp.plan_last_active = plan->last_active;
     a.segs = plan->d_segs;
     a.seg_off = plan->d_seg_off;
     a.seg_first = plan->d_first;
@@ -655,8 +677,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         lp.sel.over = ctx->tk_over;
     }
     lp.materialise = ctx->cfg.materialise != 0;
-    lp.no_l = ctx->mask_only && !prob && !lab_lo && !topk && !f32 && !lp.materialise && plan->steps_per_wg <= kMaskMaxSteps &&
-              d <= kMaskMaxClasses;      // (more classes or longer segments: prop_dense_kernel, with its denominators)
+    lp.no_l = mask_form && plan->steps_per_wg <= kMaskMaxSteps;      // (more classes or longer segments: prop_dense_kernel, with its denominators)
     if (lp.no_l) {
         rc = build_target_consts(ctx, sigma1, sigma2, temperature);
         if (rc) return rc;
@@ -921,9 +942,9 @@ int vosprop_debug_topk(vosprop_ctx* ctx, float* thr_grp, float* thr_elem, int* g
 }
 
 /* test hook (no GPU needed): segment table for TT target tiles x NT reference tiles; rows of out = (workgroup, tt, r_lo, n_steps) */
-int vosprop_debug_plan(int TT, int NT, int* out, int cap_rows) {
+int vosprop_debug_plan(int TT, int NT, int* out, int cap_rows, int last_active) {
     std::vector<std::vector<Segment>> per_wg;
-    build_segments(TT, NT, per_wg);
+    build_segments(TT, NT, per_wg, last_active);
     int n = 0;
     for (size_t b = 0; b < per_wg.size(); ++b)
         for (const Segment& sg : per_wg[b]) {
@@ -1327,7 +1348,7 @@ int vosprop_debug_partials(vosprop_ctx* ctx, int which, float* out_host, int max
     LastProp lp = ctx->last;
     if (lp.topk || lp.prob || lp.lab_lo || lp.materialise || lp.args.feat_f32) return VOSPROP_E_UNSUPPORTED;
     const Plan* plan = nullptr;
-    int rc = get_plan(ctx, lp.args.n_ref * ctx->tiles, &plan);
+    int rc = get_plan(ctx, lp.args.n_ref * ctx->tiles, &plan, lp.plan_last_active);
     if (rc) return rc;
     const size_t n = (size_t)plan->n_parts * lp.args.part_rows * kBT;
     if ((size_t)max_floats < n) return VOSPROP_E_INVALID;

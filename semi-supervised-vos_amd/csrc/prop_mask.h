@@ -309,6 +309,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
         const int n0 = r_lo - (r_lo / N) * N;
         const unsigned sp0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((A.sparse_mask >> n0) & 1ull));
 
+        // a wave whose 32 target columns all lie beyond the map (last target tile: 236 of 256 columns at 480p, 3.4 % of the launch's
+        // MFMA work) runs the STAGING-ONLY form of its role: same LDS-DMA pieces, waits and barriers, nothing else
+        const bool pad_wave = tt * kBT + wave * kColsPerWave >= A.HW;
+        const unsigned role = role_b | (pad_wave ? 2u : 0u);
         VOSPROP_MASK_STAMP(4);      // 4: target fragments scaled, loop inputs assembled
         // ---- the tile loop, its control and its rare paths: ONE statement per segment ----
         f32x16 S0, S1;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
                            "+" VOSPROP_MASK_REG_CB(CB), "+" VOSPROP_MASK_REG_CTL(CTL)
                          : VOSPROP_MASK_REG_B0(Bq0), VOSPROP_MASK_REG_B1(Bq1), VOSPROP_MASK_REG_B2(Bq2), VOSPROP_MASK_REG_B3(Bq3),
                            [n] "s"(un), [fb_lo] "s"(fb_lo), [fb_hi] "s"(fb_hi), [tb_lo] "s"(tb_lo), [tb_hi] "s"(tb_hi),
-                           [ldsa] "s"(ldsa), [lds3] "s"(lds3), [role] "s"(role_b), [tab] "s"(tab_base), [sp0] "s"(sp0)
+                           [ldsa] "s"(ldsa), [lds3] "s"(lds3), [role] "s"(role), [tab] "s"(tab_base), [sp0] "s"(sp0)
                          : VOSPROP_MASK_CLOBBERS);
         }
         VOSPROP_MASK_STAMP(5);      // 5: the first segment's tile loop is done
@@ -341,8 +345,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
             const u32x4 p = odd ? u32x4{PK[8 + o], PK[9 + o], PK[10 + o], PK[11 + o]} : u32x4{PK[o], PK[o + 1], PK[o + 2], PK[o + 3]};
             Yc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(labp, __builtin_bit_cast(bf16x8, p), Yc[cb], 0, 0, 0);
         }
-        float Mc[2];
-        {   // tile n-1: weights from its scores, labels from its ring slot
+        float Mc[2] = {0.0f, 0.0f};
+        if (!pad_wave) {   // tile n-1: weights from its scores, labels from its ring slot
             const int slot = (n_steps - 1) % kMaskRing;
             const bf16x8 lab1 = *(const bf16x8*)(smem + slot * kMaskSlot + kMaskOffLab + lane_l * 16);
 #pragma unroll

@@ -204,6 +204,8 @@ def gen_step(st, k, tag):
             return
         m0_base, m0_imm, _, _ = piece_args(i)
         e(f's_add_u32 m0, {m0_base}, {m0_imm}', 'm0')
+        if o.get('pad'):      # (no MFMA pair between the M0 write and its LDS-DMA in the staging-only form)
+            e('s_nop 0', 's')
 
     def piece_dma(i):
         if 'no_dma' in ab:
@@ -261,7 +263,7 @@ def gen_step(st, k, tag):
         if g in cvt_at:
             p = cvt_at[g]
             vcvt(p, (2 * p) % 4, (2 * p + 1) % 4)
-        if g == 9:
+        if g == 9 and not o.get('pad'):
             e(f'v_cmp_lt_f32_e32 vcc, 0x{float_bits(ALARM):08x}, v{V_MX}', 'valu', reads=[V_MX])
         if g == 10 and 'no_lm' not in ab:
             # tile q+1 opens a pixel tile or a sigma class (2 steps in 9 at N = 9): its prior tile LM[rb][cb] = coordinates x
@@ -371,7 +373,15 @@ def gen_rescale(par, tag):
     return o
 
 
-def gen_role(tag, npieces, opts):
+PAD_DROPS = ('no_mfma', 'no_valu', 'no_ds', 'no_lab', 'no_lm')
+
+
+def gen_role(tag, npieces, opts, pad=False):
+    """One role's stream.  pad = True: the STAGING-ONLY form for a wave whose 32 target columns all lie beyond the map (the last
+    target tile of a map whose pixel count is not a multiple of 256: 236 of 256 columns at 480p) - the same control, LDS-DMA pieces,
+    waits and barriers as its role (the workgroup's other waves depend on them), no fragments, no MFMA, no vector work."""
+    if pad:
+        opts = dict(opts, pad=True, ablate=tuple(opts.get('ablate', ())) + PAD_DROPS)
     st = Stream(npieces, 15, opts)
     # two rounds through the six step copies: the second is the steady state that is emitted
     for _ in range(2):
@@ -389,7 +399,7 @@ def gen_role(tag, npieces, opts):
     ahead = opts.get('ahead', AHEAD)
     init = []
     for r in range(16):
-        init += [f'v_mov_b32_e32 v{V_PK[0] + r}, 0', f'v_mov_b32_e32 v{V_S[1] + r}, {neg_inf}']
+        init += [f'v_mov_b32_e32 v{V_PK[0] + r}, 0', f'v_mov_b32_e32 v{V_S[1] + r}, ' + ('0' if pad else neg_inf)]
     for r in range(8):
         init.append(f'v_mov_b32_e32 v{V_Y + r}, 0')
     for r in range(4):
@@ -397,27 +407,31 @@ def gen_role(tag, npieces, opts):
     init += [f'v_mov_b32_e32 v{V_MX}, {neg_inf}', f'v_mov_b32_e32 v{V_MC}, 0', f'v_mov_b32_e32 v{V_MC + 1}, 0']
     # fragments 0..7 of tile 0 (slot 0; fragment f = (ks, rb) = (f >> 1, f & 1)) and its prior tile LM[rb][cb] = coordinates x
     # target-side constants of its sigma class
-    for i in range(8):
+    if pad:
+        init += [f'v_mov_b32_e32 v{V_S[0] + r}, 0' for r in range(16)]
+    for i in range(0 if pad else 8):
         reg, off = row_addr(0, i & 1, i >> 1)
         init.append(f'ds_read_b128 {vr(V_A + 4 * i, 4)}, v{reg} offset:{off}')
-    for r2 in range(2):
+    for r2 in range(0 if pad else 2):
         reg, off = coord_addr(0, r2)
         init.append(f'ds_read_b128 {vr(V_CA + 4 * r2, 4)}, v{reg} offset:{off}')
-    init += ['s_waitcnt lgkmcnt(0)', f's_cmp_lg_u32 %[sp0], 0', f's_cbranch_scc1 LI2_{tag}']
-    for sg in range(2):
-        if sg == 1:
-            init += [f's_branch LI3_{tag}', f'LI2_{tag}:']
-        for r2 in range(2):
-            for cb in range(2):
-                init.append(f'v_mfma_f32_16x16x32_bf16 {vr(s_reg(V_LM, r2, cb), 4)}, {vr(V_CA + 4 * r2, 4)}, {vr(V_CB + 8 * sg + 4 * cb, 4)}, 0')
-    init += [f'LI3_{tag}:', 's_nop 7', 's_nop 7']
+    if not pad:
+        init += ['s_waitcnt lgkmcnt(0)', f's_cmp_lg_u32 %[sp0], 0', f's_cbranch_scc1 LI2_{tag}']
+        for sg in range(2):
+            if sg == 1:
+                init += [f's_branch LI3_{tag}', f'LI2_{tag}:']
+            for r2 in range(2):
+                for cb in range(2):
+                    init.append(f'v_mfma_f32_16x16x32_bf16 {vr(s_reg(V_LM, r2, cb), 4)}, {vr(V_CA + 4 * r2, 4)}, {vr(V_CB + 8 * sg + 4 * cb, 4)}, 0')
+        init += [f'LI3_{tag}:', 's_nop 7', 's_nop 7']
     if opts.get('prio_b') is not None and npieces == 2:
         init.append(f"s_setprio {opts['prio_b']}")
     if opts.get('prio_a') is not None and npieces == 3:
         init.append(f"s_setprio {opts['prio_a']}")
     head = init + [
         # ---- segment state ----
-        f's_mov_b32 s{S_Q}, 0', f's_mov_b32 s{S_PHASE}, 0', f's_mov_b32 s{S_TBASE}, 0', f's_mov_b32 s{S_CENT}, 0',
+        f's_mov_b32 s{S_Q}, 0', f's_mov_b32 s{S_PHASE}, 0', f's_mov_b32 s{S_TBASE}, 0',
+        f's_mov_b32 s{S_CENT}, {1 if pad else 0}',      # (staging-only: nothing to centre, no first-tile boundary)
         f's_mov_b32 s{S_HMASK}, 0xffff0000', f's_mov_b32 s{S_HMASK + 1}, 0',
         f's_mov_b32 s{S_C7FFF}, 0x7fff', f's_mov_b32 s{S_CHI16}, 0xffff0000',
         f's_add_u32 s{S_WD}, %[n], 4',
@@ -457,7 +471,10 @@ def gen_role(tag, npieces, opts):
         f's_bitcmp1_b32 s{S_PHASE}, 0',
         f's_cbranch_scc1 LRESC1_{tag}',
     ]
-    tail += gen_rescale(0, tag) + [f's_branch LCENT_{tag}', f'LRESC1_{tag}:'] + gen_rescale(1, tag)
+    if not pad:
+        tail += gen_rescale(0, tag) + [f's_branch LCENT_{tag}', f'LRESC1_{tag}:'] + gen_rescale(1, tag)
+    else:
+        tail.append(f'LRESC1_{tag}:')
     tail += [
         f'LCENT_{tag}:',
         f's_mov_b32 s{S_CENT}, 1',
@@ -554,11 +571,15 @@ def stats(steady):
 def render(opts):
     a_lines, a_st = gen_role('a%=', 3, opts)
     b_lines, b_st = gen_role('b%=', 2, opts)
+    pa_lines, pa_st = gen_role('pa%=', 3, opts, pad=True)
+    pb_lines, pb_st = gen_role('pb%=', 2, opts, pad=True)
     out = []
     out.append('// GENERATED by tools/gen_mask_loop.py - do not edit; `python tools/gen_mask_loop.py` rewrites it,')
     out.append('// tests/test_host.py::test_mask_loop_is_generated checks that it is current.')
     out.append(f'// per step, role A (three LDS-DMA pieces): {stats(a_st)}')
     out.append(f'// per step, role B (two LDS-DMA pieces):   {stats(b_st)}')
+    out.append(f'// per step, staging-only role A (a wave without a target column): {stats(pa_st)}')
+    out.append(f'// per step, staging-only role B:                                   {stats(pb_st)}')
     out.append(f'#define VOSPROP_MASK_SLOT {SLOT}')
     out.append(f'#define VOSPROP_MASK_NSLOT {NSLOT}')
     out.append(f'#define VOSPROP_MASK_OFF_COORD {OFF_COORD}')
@@ -594,8 +615,11 @@ def render(opts):
     clob = [f'v{i}' for i in list(range(V_Q, V_Q + 4)) + list(range(V_LM, V_LM + 16)) + list(range(V_A, V_A + 32)) + list(range(V_CA, V_CA + 8))]
     clob += [f's{i}' for i in range(S_Q, S_BC + 2)]
     out.append('#define VOSPROP_MASK_CLOBBERS ' + ', '.join(f'"{c}"' for c in clob) + ', "vcc", "scc", "memory"')
-    # ONE statement per segment holds both roles and the rare paths: %[role] != 0 takes the second stream
-    lines = ['s_cmp_lg_u32 %[role], 0', 's_cbranch_scc1 LROLEB_%='] + a_lines + ['s_branch LEND_%=', 'LROLEB_%=:'] + b_lines + ['LEND_%=:']
+    # ONE statement per segment holds the roles and the rare paths: %[role] = 0 A, 1 B, 2 / 3 their staging-only forms
+    lines = ['s_cmp_eq_u32 %[role], 1', 's_cbranch_scc1 LROLEB_%=', 's_cmp_eq_u32 %[role], 2', 's_cbranch_scc1 LROLEPA_%=',
+             's_cmp_eq_u32 %[role], 3', 's_cbranch_scc1 LROLEPB_%=']
+    lines += a_lines + ['s_branch LEND_%=', 'LROLEB_%=:'] + b_lines + ['s_branch LEND_%=', 'LROLEPA_%=:'] + pa_lines
+    lines += ['s_branch LEND_%=', 'LROLEPB_%=:'] + pb_lines + ['LEND_%=:']
     out.append('#define VOSPROP_MASK_LOOP \\')
     out.append(' \\\n'.join('    "' + ln + '\\n"' for ln in lines))
     return '\n'.join(out) + '\n'

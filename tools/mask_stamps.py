@@ -49,10 +49,12 @@ def main():
     TT = (Hd * Wd + 255) // 256
     NT = st['n_ref'] * ((Hd * Wd + 31) // 32)
     L.vosprop_debug_plan.restype = ctypes.c_int
-    L.vosprop_debug_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
-    nrow = L.vosprop_debug_plan(TT, NT, None, 0)
+    L.vosprop_debug_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int]
+    la = -(-(Hd * Wd - (TT - 1) * 256) // 32)      # waves of the last target tile that hold a column of the map
+    la = la if la < 8 else 0
+    nrow = L.vosprop_debug_plan(TT, NT, None, 0, la)
     pb = (ctypes.c_int * (4 * nrow))()
-    L.vosprop_debug_plan(TT, NT, pb, nrow)
+    L.vosprop_debug_plan(TT, NT, pb, nrow, la)
     rows = np.ctypeslib.as_array(pb).reshape(nrow, 4)
     nseg = np.bincount(rows[:, 0], minlength=st['workgroups'])
     steps = np.bincount(rows[:, 0], weights=rows[:, 3], minlength=st['workgroups'])
@@ -62,6 +64,16 @@ def main():
     for x in range(8):
         sel = (np.arange(st['workgroups']) % 8) == x
         print(f'  XCD slot {x}: exit mean {us[sel, 7].mean():7.2f} max {us[sel, 7].max():7.2f}')
+    # one-segment workgroups by target tile: the LAST tile's waves beyond the map run the staging-only form (prop_mask.h)
+    first_tt = np.full(st['workgroups'], -1)
+    for b, tt, _, _ in rows[::-1]:
+        first_tt[b] = tt
+    one = nseg == 1
+    for name, sel in (('last target tile', one & (first_tt == TT - 1)), ('other target tiles', one & (first_tt != TT - 1))):
+        if sel.any():
+            loop = us[sel, 5] - us[sel, 4]
+            print(f'  one-segment workgroups on the {name}: {int(sel.sum()):3d}, tile steps {steps[sel].mean():6.1f}, loop {loop.mean():7.2f} us '
+                  f'= {1e3 * (loop / steps[sel]).mean():6.1f} ns per step, exit mean {us[sel, 7].mean():7.2f}')
     d = np.diff(us, axis=1)
     print('  phase lengths (mean us): ' + ', '.join(f'{names[k]}->{names[k + 1]} {d[:, k].mean():.2f}' for k in range(7)))
     eng.close()
