@@ -41,7 +41,7 @@ def main():
     s = buf.reshape(-1, 8).astype(np.int64)
     z = s[:, 0].min()
     us = (s - z) / 100.0
-    names = ['entry', 'segment record', 'prologue issued', 'prologue landed', 'loop inputs ready', 'first loop done', 'last partial stored', 'exit']
+    names = ['entry', 'segment record*', 'prologue issued', 'prologue landed', 'loop inputs ready', 'first loop done', 'last partial stored', 'exit']
     print(f'{Hd}x{Wd}: {st["workgroups"]} workgroups, {st["tiles_per_wg"]} tile steps each; us after the first workgroup entered the kernel')
     for k, nm in enumerate(names):
         print(f'  {k} {nm:22s} min {us[:, k].min():7.2f}  mean {us[:, k].mean():7.2f}  max {us[:, k].max():7.2f}')
@@ -74,8 +74,10 @@ def main():
             loop = us[sel, 5] - us[sel, 4]
             print(f'  one-segment workgroups on the {name}: {int(sel.sum()):3d}, tile steps {steps[sel].mean():6.1f}, loop {loop.mean():7.2f} us '
                   f'= {1e3 * (loop / steps[sel]).mean():6.1f} ns per step, exit mean {us[sel, 7].mean():7.2f}')
-    d = np.diff(us, axis=1)
-    print('  phase lengths (mean us): ' + ', '.join(f'{names[k]}->{names[k + 1]} {d[:, k].mean():.2f}' for k in range(7)))
+    # (* stamp 1 is rewritten by every segment: it is the LAST segment's record; stamps 2-5 are the first segment's.  Phase lengths
+    # are therefore taken over the one-segment workgroups)
+    d = np.diff(us[one], axis=1)
+    print('  phase lengths, one-segment workgroups (mean us): ' + ', '.join(f'{names[k]}->{names[k + 1]} {d[:, k].mean():.2f}' for k in range(7)))
     eng.close()
 
 

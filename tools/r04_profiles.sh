@@ -31,8 +31,10 @@ bash tools/traffic_pmc.sh davis480p_r50_dense --stateful > $O/traffic_480p.log 2
 bash tools/traffic_pmc.sh ytvos720p_r50_dense --stateful --hd 90 --wd 160 > $O/traffic_720p.log 2>&1
 bash tools/traffic_pmc.sh davis480p_r50_top20_ref5 --stateful --ref-num 5 --topk 20 > $O/traffic_topk.log 2>&1
 bash tools/traffic_pmc.sh pair240p_r18 --stateful --hd 30 --wd 54 > $O/traffic_240p.log 2>&1
+# (top-k on the bench CLIP, not flat logits: the data-dependent pass 2 walks far fewer tiles there)
+TRAFFIC_CMD="python bench.py --workload davis480p_r50_top20_ref5 --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end --no-miopen-find" bash tools/traffic_pmc.sh davis480p_r50_top20_ref5_clip > $O/traffic_topk_clip.log 2>&1
 bash tools/traffic_pmc.sh ytvos720p_r50_dense_materialised --stateful --hd 90 --wd 160 --materialise > $O/traffic_mat.log 2>&1
-for t in davis480p_r50_dense ytvos720p_r50_dense davis480p_r50_top20_ref5 pair240p_r18 ytvos720p_r50_dense_materialised; do cp gpurun_out/traffic_$t/traffic.json $O/traffic_$t.json; cp gpurun_out/traffic_$t/summary.txt $O/traffic_$t.txt; done
+for t in davis480p_r50_dense ytvos720p_r50_dense davis480p_r50_top20_ref5 davis480p_r50_top20_ref5_clip pair240p_r18 ytvos720p_r50_dense_materialised; do cp gpurun_out/traffic_$t/traffic.json $O/traffic_$t.json; cp gpurun_out/traffic_$t/summary.txt $O/traffic_$t.txt; done
 echo "traffic done"
 fi
 if [[ "$PARTS" == *" 4 "* ]]; then

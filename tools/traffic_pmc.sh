@@ -2,6 +2,8 @@
 # HBM-side traffic of the propagation kernel(s) of one workload: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes, as
 # MI355X_MICROARCH.md prescribes (plus GRBM_GUI_ACTIVE, TCC hit / miss).  Usage (on the GPU box):
 #     bash tools/traffic_pmc.sh <tag> [prop_bench args]        e.g.  bash tools/traffic_pmc.sh davis480p_r50_dense --stateful
+# TRAFFIC_CMD="python bench.py --workload ... --steps 20 --warmup 5 --no-cpu-baseline --no-end-to-end" profiles that command instead of
+# tools/prop_bench.py (the bench CLIP rather than flat logits; the last 6 dispatches of each kernel are still what is averaged).
 # Writes gpurun_out/traffic_<tag>/{summary.txt,traffic.json} (copy the json to profiles/r04_prop_kernel_traffic_<tag>.json;
 # it carries the hash of the kernel sources it was taken with - bench.py quotes it only while that hash matches the build).
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -12,10 +14,14 @@ rm -rf $O && mkdir -p $O
 i=0
 for set in "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_GUI_ACTIVE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
+  if [ -n "$TRAFFIC_CMD" ]; then
+    (cd $R && timeout -k 10 500 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- $TRAFFIC_CMD > $O/p$i.log 2>&1) || echo "pass $i failed"
+  else
   timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python $R/tools/prop_bench.py --iters 5 "$@" > $O/p$i.log 2>&1 || echo "pass $i failed"
+  fi
 done
 python $R/tools/pmc_summary.py $O/p1 $O/p2 $O/p3 | tee $O/summary.txt
-python - "$O/summary.txt" "$tag" "$*" "$R" <<'PY'
+python - "$O/summary.txt" "$tag" "${TRAFFIC_CMD:-tools/prop_bench.py --iters 5 $*}" "$R" <<'PY'
 import collections, json, re, sys
 sys.path.insert(0, sys.argv[4])
 import bench
@@ -34,7 +40,7 @@ for k, c in rows.items():
                      'l2_hit_rate': c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']) if 'TCC_HIT_sum' in c else None})
         tot += b
         us += c.get('kernel_us(profiled)') or 0.0
-out = {'workload': sys.argv[2], 'kernel_source_hash': bench.kernel_source_hash(), 'bench_args': 'tools/prop_bench.py --iters 5 ' + sys.argv[3], 'kernels': kern,
+out = {'workload': sys.argv[2], 'kernel_source_hash': bench.kernel_source_hash(), 'bench_args': sys.argv[3], 'kernels': kern,
        'traffic_bytes_per_launch': tot, 'hbm_gb_per_s': tot / us / 1e3 if us else None,
        'how': 'tools/traffic_pmc.sh: rocprofv3 --kernel-trace --pmc, FETCH_SIZE and WRITE_SIZE in separate passes, mean of the last 6 '
               'dispatches (full-N propagations); FETCH_SIZE x2 (gfx950: wide 16 B/lane streams are counted at half, '
