@@ -63,6 +63,7 @@ struct Plan {
     int grid = 0;             // workgroups = 8 * wg_per_xcd
     int wg_per_xcd = 0;
     int steps_per_wg = 0;     // reference tiles the busiest workgroup walks (stats)
+    int max_seg_steps = 0;    // the longest segment (prop_mask_kernel builds one control table per segment: kMaskMaxSteps)
     int n_parts = 0;          // total partial slots = number of segments
     int* d_off = nullptr;     // [TT + 1]
     std::vector<int> h_off;   // host copy of d_off
@@ -390,6 +391,7 @@ int get_plan(vosprop_ctx* ctx, int NT, const Plan** out, int last_active = 0) {
             sg.slot = next[(size_t)sg.tt]++;
             segs.push_back(sg);
             steps += sg.n_steps;
+            if (sg.n_steps > p.max_seg_steps) p.max_seg_steps = sg.n_steps;
         }
         if (steps > p.steps_per_wg) p.steps_per_wg = steps;
         seg_off[(size_t)b + 1] = (int)segs.size();
@@ -589,7 +591,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
     const int last_active = (last_cols + kColsPerWave - 1) / kColsPerWave;
     const Plan* plan = nullptr;
     int rc = get_plan(ctx, n_ref * ctx->tiles, &plan, mask_form && last_active < kWaves ? last_active : 0);
-    if (!rc && mask_form && plan->steps_per_wg > kMaskMaxSteps) rc = get_plan(ctx, n_ref * ctx->tiles, &plan);   // -> prop_dense_kernel
+    if (!rc && mask_form && plan->max_seg_steps > kMaskMaxSteps) rc = get_plan(ctx, n_ref * ctx->tiles, &plan);   // -> prop_dense_kernel
     if (rc) return rc;
     lp.plan_last_active = plan->last_active;
     a.segs = plan->d_segs;
@@ -677,7 +679,7 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         lp.sel.over = ctx->tk_over;
     }
     lp.materialise = ctx->cfg.materialise != 0;
-    lp.no_l = mask_form && plan->steps_per_wg <= kMaskMaxSteps;      // (more classes or longer segments: prop_dense_kernel, with its denominators)
+    lp.no_l = mask_form && plan->max_seg_steps <= kMaskMaxSteps;      // (more classes or longer segments: prop_dense_kernel, with its denominators)
     if (lp.no_l) {
         rc = build_target_consts(ctx, sigma1, sigma2, temperature);
         if (rc) return rc;

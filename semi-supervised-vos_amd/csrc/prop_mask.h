@@ -330,7 +330,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
                            [ldsa] "s"(ldsa), [lds3] "s"(lds3), [role] "s"(role), [tab] "s"(tab_base), [sp0] "s"(sp0)
                          : VOSPROP_MASK_CLOBBERS);
         }
-        VOSPROP_MASK_STAMP(5);      // 5: the first segment's tile loop is done
+        // 5: the first segment's tile loop is done.  Taken into scalar registers without a C++ branch and stored with stamp 6: a branch right
+        // behind the statement (80 hard-bound output registers live) makes hipcc park 16 of them in scratch - 64 B per lane and
+        // segment, +12 MB of HBM writes per 480p launch (seen in the WRITE_SIZE counter, not in the time)
+        unsigned long long t_loop_done;
+        asm volatile("s_cmp_eq_u64 %1, 0\n\ts_cbranch_scc1 LNOSTAMP%=\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\nLNOSTAMP%=:"
+                     : "=s"(t_loop_done) : "s"(A.dbg) : "scc", "memory");
         const bool centred = n_steps >= 2;      // the first tile went through the rescale path (boundary 2)
 
         // ---- the segment's last two tiles have no chain to hide under ----
@@ -345,8 +350,8 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
             const u32x4 p = odd ? u32x4{PK[8 + o], PK[9 + o], PK[10 + o], PK[11 + o]} : u32x4{PK[o], PK[o + 1], PK[o + 2], PK[o + 3]};
             Yc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(labp, __builtin_bit_cast(bf16x8, p), Yc[cb], 0, 0, 0);
         }
-        float Mc[2] = {0.0f, 0.0f};
-        if (!pad_wave) {   // tile n-1: weights from its scores, labels from its ring slot
+        float Mc[2];
+        {   // tile n-1: weights from its scores, labels from its ring slot (a staging-only wave: zeros in, finite values out, not stored)
             const int slot = (n_steps - 1) % kMaskRing;
             const bf16x8 lab1 = *(const bf16x8*)(smem + slot * kMaskSlot + kMaskOffLab + lane_l * 16);
 #pragma unroll
@@ -381,15 +386,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
         for (int cb = 0; cb < 2; ++cb) {
             float* part = A.part + ((size_t)part_slot * A.part_rows) * kBT + wave * kColsPerWave + 16 * cb + j16;
             if (kb == 0) {
-                part[0] = Mc[cb] / c;
+                part[0] = pad_wave ? 0.0f : Mc[cb] / c;
                 part[kBT] = 0.0f;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int cls = 4 * kb + i;
-                if (cls < A.d) part[(size_t)(2 + cls) * kBT] = Yc[cb][i];
+                if (cls < A.d) part[(size_t)(2 + cls) * kBT] = pad_wave ? 0.0f : Yc[cb][i];
             }
         }
+        if (A.dbg && tid == 0 && si == seg0) A.dbg[(size_t)blockIdx.x * 8 + 5] = t_loop_done;
         VOSPROP_MASK_STAMP(6);      // 6: the (last) segment's partial is stored
     }
     {

@@ -483,12 +483,13 @@ def test_mask_only_step_at_full_480p_vs_oracle(vos, dev, peaky):
     assert len(np.unique(cls_hist[20])) >= 3        # the objects survive 20 propagations
 
 
-def test_mask_only_step_at_720p_matches_the_oracle(vos, dev):
+@pytest.mark.parametrize('H,W', [(720, 1280), (960, 1704)], ids=['720p', '960p'])
+def test_mask_only_step_at_720p_matches_the_oracle(vos, dev, H, W):
     """720p (90x160 map, N = 9: ~500 tile steps per segment, eight control-table blocks): a 19-frame roll-out of mask-only steps -
     the engine must report prop_mask_kernel as the kernel it launched (vosprop_stats.kernel_id, set where the launch is decided); at frames 17
     and 18 (frame_idx > 15: both sigma classes) the class map must be the arg-max of the oracle's predict_columns, fed with the
-    engine's own label history, on every sampled column with a clear top-2 margin."""
-    H, W = 720, 1280
+    engine's own label history, on every sampled column with a clear top-2 margin.  960p (120x213): a workgroup walks 2 800 tile
+    steps in segments of ~900 - more than ONE control table holds (1 981), which is a limit per segment, not per workgroup."""
     Hd, Wd = vos.feature_map_size(H, W)
     HW = Hd * Wd
     rs = np.random.RandomState(720)
@@ -516,6 +517,8 @@ def test_mask_only_step_at_720p_matches_the_oracle(vos, dev):
     eng.close()
     assert st['n_ref'] == 9 and st['hw'] == HW
     assert st['kernel_id'] == vos._native.KERNEL_MASK and st['kernel'] == 'prop_mask_kernel', st
+    if H == 960:
+        assert st['tiles_per_wg'] > 1981, st
     onehot = np.zeros((d, T, HW), np.float32)
     for t in range(T):
         onehot[cls_hist[t], t, np.arange(HW)] = 1.0

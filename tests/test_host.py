@@ -445,22 +445,39 @@ def test_work_plan_covers_every_unit_once(vos, TT, NT, la):
         assert collections.Counter(rows[:, 0].tolist()).most_common(1)[0][1] == 1 and len(set(rows[:, 0].tolist())) == 256
 
 
-def test_no_compiler_generated_m0_reader_in_the_propagation_kernels(tmp_path):
-    """glds16s / glds16s2 (csrc/prop_bf16.h) set M0 inside an asm statement and do not restore it (M0 is a reserved register: it
-    cannot be put on a clobber list).  That is only sound while hipcc itself emits nothing that READS M0 in those kernels
-    (v_movrel / s_movrel indirect indexing, s_sendmsg, GDS ops, its own `... lds` loads): this test compiles the engine to ISA and
-    fails if any line of a propagation kernel mentions m0 outside the three forms the asm statements themselves produce."""
-    import re
+@pytest.fixture(scope='module')
+def engine_isa(tmp_path_factory):
+    """csrc/engine.hip compiled to gfx950 ISA text with the build's own flags (__graft_entry__.build)."""
     import shutil
     import subprocess
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not Path(hipcc).exists():
         pytest.skip('no hipcc')
     src = ROOT / 'semi-supervised-vos_amd' / 'csrc'
-    out = tmp_path / 'engine.s'
-    subprocess.run([hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fno-slp-vectorize', '-S', '--cuda-device-only', '-o',
-                    str(out), 'engine.hip'], cwd=src, check=True, capture_output=True, timeout=600)
-    text = out.read_text()
+    out = tmp_path_factory.mktemp('isa') / 'engine.s'
+    subprocess.run([hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-fno-slp-vectorize', '-mllvm', '-amdgpu-mfma-vgpr-form=1', '-S',
+                    '--cuda-device-only', '-o', str(out), 'engine.hip'], cwd=src, check=True, capture_output=True, timeout=600)
+    return out.read_text()
+
+
+def test_mask_kernel_keeps_its_registers_out_of_scratch(engine_isa):
+    """prop_mask_kernel's tile loop is one asm statement with ~200 hard-bound registers; hipcc parks values it cannot place in
+    scratch.  20 bytes per lane (a few scalars-in-VGPRs around the statement) is the known floor; round 4 once grew to 84 - a C++
+    branch right behind the statement made hipcc spill 16 output registers per segment, +12 MB of HBM writes per 480p launch that
+    only the WRITE_SIZE counter showed.  This keeps it from coming back unseen."""
+    import re
+    m = re.search(r'\.amdhsa_kernel _ZN7vosprop16prop_mask_kernel.*?\.amdhsa_private_segment_fixed_size (\d+)', engine_isa, re.S)
+    assert m, 'prop_mask_kernel not found in the ISA'
+    assert int(m.group(1)) <= 32, f'prop_mask_kernel uses {m.group(1)} bytes of scratch per lane'
+
+
+def test_no_compiler_generated_m0_reader_in_the_propagation_kernels(engine_isa):
+    """glds16s / glds16s2 (csrc/prop_bf16.h) set M0 inside an asm statement and do not restore it (M0 is a reserved register: it
+    cannot be put on a clobber list).  That is only sound while hipcc itself emits nothing that READS M0 in those kernels
+    (v_movrel / s_movrel indirect indexing, s_sendmsg, GDS ops, its own `... lds` loads): this test compiles the engine to ISA and
+    fails if any line of a propagation kernel mentions m0 outside the three forms the asm statements themselves produce."""
+    import re
+    text = engine_isa
     ours = (re.compile(r'^\s*s_add_u32 m0, \S+, \S+\s*$'), re.compile(r'^\s*s_mov_b32 m0, \S+\s*$'),
             re.compile(r'^\s*s_mov_b32 \S+, m0\s*$'))
     kernel, bad, seen = None, [], 0
