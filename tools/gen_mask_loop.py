@@ -271,20 +271,28 @@ def gen_step(st, k, tag):
             # block reads the two coordinate fragments itself and drains the LDS queue (lgkmcnt(0): the queue model is untouched)
             e(f's_bitcmp1_b32 s{S_RAWA}, 0', 's')
             e(f's_cbranch_scc1 LM{k}_{tag}', 'branch')
+            at = len(st.ins)                      # (the block is modelled, for the hazard check, as if it ran inline right here)
             st.label(f'LW{k}_{tag}')
             blk = [f'LM{k}_{tag}:']
+            model = []
             for r2 in range(2):
                 reg, off = coord_addr(nxt, r2)
                 blk.append(f'ds_read_b128 {vr(V_CA + 4 * r2, 4)}, v{reg} offset:{off}')
+                model.append(Ins(blk[-1], 'ds', reads=[reg], writes=regs(V_CA + 4 * r2, 4)))
             blk += ['s_waitcnt lgkmcnt(0)', f's_bitcmp1_b32 s{S_RAWA}, 1', f's_cbranch_scc1 LV{k}_{tag}']
+            model += [Ins(t, 'wait' if 'waitcnt' in t else 's') for t in blk[-3:]]
             for sg in range(2):
                 if sg == 1:
                     blk += [f's_branch LW{k}_{tag}', f'LV{k}_{tag}:']
                 for r2 in range(2):
                     for cb in range(2):
-                        blk.append(f'v_mfma_f32_16x16x32_bf16 {vr(s_reg(V_LM, r2, cb), 4)}, {vr(V_CA + 4 * r2, 4)}, {vr(V_CB + 8 * sg + 4 * cb, 4)}, 0')
+                        dst, a_, b_ = s_reg(V_LM, r2, cb), V_CA + 4 * r2, V_CB + 8 * sg + 4 * cb
+                        blk.append(f'v_mfma_f32_16x16x32_bf16 {vr(dst, 4)}, {vr(a_, 4)}, {vr(b_, 4)}, 0')
+                        if sg == 1:               # (one sigma branch runs: four MFMAs, then the branch back)
+                            model.append(Ins(blk[-1], 'mfma', reads=set(regs(a_, 4)) | set(regs(b_, 4)), writes=regs(dst, 4)))
             blk.append(f's_branch LW{k}_{tag}')
-            st.outlined.append(blk)
+            model.append(Ins(blk[-1], 'branch'))
+            st.outlined.append((at, blk, model))
         if g == 12 and 'no_lab' not in ab:
             reg, off = lane_addr(prv, OFF_LAB)
             st.ds_read('LAB', V_LAB, 4, reg, off)
@@ -394,6 +402,14 @@ def gen_role(tag, npieces, opts, pad=False):
     assert st.fifo == fifo_before, (st.fifo, fifo_before)
     steady = st.ins[start:]
     check_hazards(st.ins, start)
+    # ... and once more with every out-of-line block of the steady round run inline where its branch sits (the worst case for the
+    # distances behind it: the common path has the same instructions minus the block)
+    worst, prev = [], 0
+    for at, _, model in sorted(st.outlined, key=lambda x: x[0]):
+        worst += st.ins[prev:at] + model
+        prev = at
+    worst += st.ins[prev:]
+    check_hazards(worst, start)
     thr = f'0x{float_bits(ALARM):08x}'
     neg_inf = '0xff800000'
     ahead = opts.get('ahead', AHEAD)
@@ -496,7 +512,7 @@ def gen_role(tag, npieces, opts, pad=False):
         f's_branch LCTL_{tag}',
         f'LDONE_{tag}:',
     ]
-    lines = head + [i.text for i in steady] + [ln for blk in st.outlined for ln in blk] + tail
+    lines = head + [i.text for i in steady] + [ln for _, blk, _ in st.outlined for ln in blk] + tail
     return lines, steady
 
 
