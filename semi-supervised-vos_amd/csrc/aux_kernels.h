@@ -549,7 +549,7 @@ struct TopkCombineArgs {
     int k, d, HW, HWp, n_ref, chunks, cap;
     float c;
     unsigned* over;           // [3] clamp counters (common.h PropArgs.tk_over)
-    int debug;                // dev switch (VOSPROP_TK_DEBUG): 1 = radix selection on all keys, no lane-maximum bound / compaction
+    int force_radix;          // test switch (VOSPROP_TK_FORCE_RADIX): 1 = every column takes the overflow fallback (radix selection on all keys)
 };
 
 constexpr int kTkComNV = 10;      // groups per quarter-wave the combine kernel holds: 40 dumped groups (640 exponents) per pixel
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(kTkComWaves * 64) void topk_combine2_kernel(const T
             base += __builtin_popcountll(m);
         }
         unsigned T;
-        if (base <= kTkComCap && !(a.debug & 1)) {
+        if (base <= kTkComCap && !(a.force_radix & 1)) {
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
             unsigned k2[2];

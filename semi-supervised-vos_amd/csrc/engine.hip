@@ -730,8 +730,10 @@ int propagate(vosprop_ctx* ctx, Ring& ring, const int* slots, int n_ref, int fra
         for (int n = 0; n < n_ref; ++n) ca.slot[n] = slots[n];
         ca.k = topk; ca.d = d; ca.HW = ctx->HW; ca.HWp = ctx->HWp; ca.n_ref = n_ref; ca.chunks = a.tk_chunks; ca.cap = a.tk_cap;
         ca.c = a.c;
-        static const int tk_debug = getenv("VOSPROP_TK_DEBUG") ? atoi(getenv("VOSPROP_TK_DEBUG")) : 0;
-        ca.debug = tk_debug;
+        // VOSPROP_TK_FORCE_RADIX=1 (tests/test_gpu_topk.py): every column takes the radix selection over ALL its keys - the path a
+        // column falls back to when its candidates overflow the compaction buffer (counted in vosprop_topk_overflows)
+        static const int tk_force_radix = getenv("VOSPROP_TK_FORCE_RADIX") ? atoi(getenv("VOSPROP_TK_FORCE_RADIX")) : 0;
+        ca.force_radix = tk_force_radix;
         hipLaunchKernelGGL(topk_combine2_kernel, dim3((ctx->HWp + kTkComWaves - 1) / kTkComWaves), dim3(kTkComWaves * 64), 0, s, ca, pred, cls, new_lab_hi,
                            new_lab_lo);
     } else {
@@ -923,24 +925,6 @@ int vosprop_debug_pointwise_candidates(const void* x, const void* weight, const 
                                   (PwCandidateReport*)rows, cap_rows, &n, repeats, full != 0);
     if (rc == 0) return n;
     return rc == 1 ? VOSPROP_E_INVALID : rc == 3 ? VOSPROP_E_UNSUPPORTED : VOSPROP_E_HIP;
-}
-
-/* test hook (GPU, not part of include/vosprop.h): the top-k thresholds and the number of groups pass 2 dumped per target pixel, of
- * the last top-k propagation on ctx.  thr_grp / thr_elem: HW floats each; groups: HW ints. */
-int vosprop_debug_topk(vosprop_ctx* ctx, float* thr_grp, float* thr_elem, int* groups) {
-    if (!ctx || !ctx->last.valid || !ctx->last.topk) return VOSPROP_E_STATE;
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipMemcpy(thr_grp, ctx->tk_thr, (size_t)ctx->HW * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(ctx, hipMemcpy(thr_elem, ctx->tk_thr_elem, (size_t)ctx->HW * 4, hipMemcpyDeviceToHost));
-    const int units = 2 * ctx->last.args.tk_chunks;
-    std::vector<unsigned> cnt((size_t)ctx->HW * units);
-    HIP_TRY(ctx, hipMemcpy(cnt.data(), ctx->tk_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
-    for (int t = 0; t < ctx->HW; ++t) {
-        int n = 0;
-        for (int u = 0; u < units; ++u) n += (int)cnt[(size_t)t * units + u];
-        groups[t] = n;
-    }
-    return VOSPROP_OK;
 }
 
 /* test hook (no GPU needed): segment table for TT target tiles x NT reference tiles; rows of out = (workgroup, tt, r_lo, n_steps) */
@@ -1167,10 +1151,9 @@ int vosprop_step(vosprop_ctx* ctx, const void* feat_dev, int feat_dtype, float* 
     const size_t lab_slot = (size_t)ctx->tiles * 2 * 64 * 8;
     // Channels-last bf16 features on the dense bf16 path are not copied into the ring up front: the propagation kernel reads the
     // target frame where the encoder left it and combine_kernel carries the copy (one launch and one dispatch gap fewer per frame)
-    static const bool no_fuse_push = getenv("VOSPROP_FUSE_PUSH") && atoi(getenv("VOSPROP_FUSE_PUSH")) == 0;
     const bool hwc16 = feat_dtype == (VOSPROP_DT_BF16 | VOSPROP_LAYOUT_HWC) || feat_dtype == (VOSPROP_DT_F16 | VOSPROP_LAYOUT_HWC);
     const bool fuse_push = f > 0 && hwc16 && ctx->cfg.precision == VOSPROP_PREC_BF16 &&
-                           ctx->cfg.topk == 0 && !ctx->cfg.materialise && !no_fuse_push;
+                           ctx->cfg.topk == 0 && !ctx->cfg.materialise;
     int rc = fuse_push ? VOSPROP_OK : push_features(ctx, feat_dev, feat_dtype, R, slot, s);
     if (rc) return rc;
     if (f == 0) {   // reference inference_utils.py:33-48: frame 0 only seeds the history

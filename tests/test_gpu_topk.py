@@ -175,3 +175,49 @@ def test_topk_capacity_clamps_do_not_fire_on_flat_logits(vos, dev, k):
     want = vo.predict_columns(feats[:fi], feats[fi], oh[:, :fi], 8.0, 21.0, fi, 40, 5, 1.0, False, cols, topk=k).numpy()
     tot = np.maximum(want.sum(0), 1e-30)
     assert np.max(np.abs(got[:, cols] - want) / tot) <= 2e-2, np.max(np.abs(got[:, cols] - want) / tot)
+
+
+_FORCED_RADIX_CHILD = r'''
+import importlib, json, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from oracle import vos_oracle as vo
+vos = importlib.import_module('semi-supervised-vos_amd')
+Hd, Wd, T, d, fi, k = 23, 31, 7, 4, 6, 20
+HW = Hd * Wd
+rs = np.random.RandomState(77)
+feats = torch.from_numpy((rs.randn(T, 256, Hd, Wd) * 0.25).astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+lab = rs.randint(0, d, size=(T, HW))
+oh = np.zeros((d, T, HW), np.float32)
+tt, pp = np.meshgrid(np.arange(T), np.arange(HW), indexing='ij')
+oh[lab, tt, pp] = 1.0
+dev = torch.device('cuda', 0)
+eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=5, topk=k)
+got = eng.predict(torch.from_numpy(feats[:fi]).to(dev), torch.from_numpy(feats[fi]).to(dev), torch.from_numpy(oh[:, :fi]).to(dev),
+                  fi, 40, 5, 1.0, 8.0, 21.0, False).cpu().numpy()
+over = eng.topk_overflows()
+eng.close()
+want = vo.predict_columns(feats[:fi], feats[fi], oh[:, :fi], 8.0, 21.0, fi, 40, 5, 1.0, False, np.arange(HW), topk=k).numpy()
+tot = np.maximum(want.sum(0), 1e-30)
+print(json.dumps({'err': float(np.max(np.abs(got.reshape(d, HW) - want) / tot)), 'over': list(over)}))
+'''
+
+
+def test_topk_select_radix_fallback_matches_the_oracle(tmp_path):
+    """topk_combine2_kernel finds a column's k-th largest key among the candidates it compacted into LDS; a column with more
+    candidates than that buffer holds falls back to a radix selection over ALL its keys.  Natural inputs never get there (the
+    overflow counters of the tests above read zero), so the fallback is FORCED here for every column (VOSPROP_TK_FORCE_RADIX=1, read
+    once per process: hence the child process) and checked against the oracle's top-k restatement like the default path."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    script = tmp_path / 'child.py'
+    script.write_text(_FORCED_RADIX_CHILD)
+    env = dict(os.environ, VOSPROP_TK_FORCE_RADIX='1')
+    r = subprocess.run([sys.executable, str(script), str(root)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['err'] <= 2e-2, out
