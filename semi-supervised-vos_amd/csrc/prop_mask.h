@@ -197,7 +197,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
             }
 
         // "tile -1" takes its labels from the last slot: zero them (0 x NaN)
-        if (tid_l < kMaskLab / 16) *(f32x4*)(smem + (kMaskRing - 1) * kMaskSlot + kMaskOffLab + tid_l * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (the zero is made HERE, opaquely: as a loop invariant hipcc kept the zero vector in scratch, and its reload's vmcnt(0) held
+        // the first tiles' LDS-DMA back until the target fragments had landed)
+        float zero = 0.0f;
+        asm volatile("" : "+v"(zero));
+        if (tid_l < kMaskLab / 16) *(f32x4*)(smem + (kMaskRing - 1) * kMaskSlot + kMaskOffLab + tid_l * 16) = f32x4{zero, zero, zero, zero};
 
         // ---- tiles 0 .. kMaskAhead-1 -> slots 0 .. kMaskAhead-1, issued BEFORE the control table is built (their source offsets are
         // computed here directly): the table's arithmetic and its barrier then run under the memory latency of these pieces and
@@ -242,6 +246,12 @@ __global__ __launch_bounds__(kWaves * 64, 2) void prop_mask_kernel(const PropArg
         for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(Braw[i]));
         VOSPROP_MASK_STAMP(2);      // 2: everything of the prologue is issued, the control table is built
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (target fragments, constants and the first tiles' pieces)
+        // the next segment's record has landed too: into scalar registers now (as four vector registers it lived across the loop
+        // statement - in scratch, with a dependent scratch load at every segment start)
+        sg_next.tt = __builtin_amdgcn_readfirstlane(sg_next.tt);
+        sg_next.r_lo = __builtin_amdgcn_readfirstlane(sg_next.r_lo);
+        sg_next.n_steps = __builtin_amdgcn_readfirstlane(sg_next.n_steps);
+        sg_next.slot = __builtin_amdgcn_readfirstlane(sg_next.slot);
         VOSPROP_MASK_STAMP(3);      // 3: ... and has landed
         // c folded into the target side: T' = bf16(c T) (f16 features are converted on the way, one rounding); Bq = [cb][ks] x 4
         u32x16 Bq0, Bq1, Bq2, Bq3;

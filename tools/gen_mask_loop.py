@@ -185,7 +185,7 @@ def gen_step(st, k, tag):
         e(f'v_cvt_pk_bf16_f32 v{dst}, v{V_Q + qa}, v{V_Q + qb}', 'valu', reads=[V_Q + qa, V_Q + qb], writes=[dst])
 
     def vmax(i):
-        if 'no_valu' in ab:
+        if 'no_valu' in ab or 'no_alarm' in ab:
             return
         if i == 0:
             e(f'v_max_f32 v{V_MX}, v{P}, v{P + 1}', 'valu', reads=[P, P + 1], writes=[V_MX])
@@ -263,7 +263,7 @@ def gen_step(st, k, tag):
         if g in cvt_at:
             p = cvt_at[g]
             vcvt(p, (2 * p) % 4, (2 * p + 1) % 4)
-        if g == 9 and not o.get('pad'):
+        if g == 9 and not o.get('pad') and 'no_alarm' not in ab:
             e(f'v_cmp_lt_f32_e32 vcc, 0x{float_bits(ALARM):08x}, v{V_MX}', 'valu', reads=[V_MX])
         if g == 10 and 'no_lm' not in ab:
             # tile q+1 opens a pixel tile or a sigma class (2 steps in 9 at N = 9): its prior tile LM[rb][cb] = coordinates x
@@ -645,7 +645,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--check', action='store_true')
     ap.add_argument('--out', default=str(OUT))
-    ap.add_argument('--ablate', default='', help='comma list of no_dma,no_barrier,no_valu,no_ds,no_lab,no_mfma,no_lm (timing experiments: WRONG results)')
+    ap.add_argument('--ablate', default='', help='comma list of no_dma,no_barrier,no_valu,no_ds,no_lab,no_mfma,no_lm,no_alarm (timing experiments: WRONG results)')
     ap.add_argument('--opt', action='append', default=[], help='key=value generator options (python literals)')
     args = ap.parse_args()
     opts = {'ablate': tuple(x for x in args.ablate.split(',') if x)}
