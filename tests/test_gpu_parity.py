@@ -384,6 +384,37 @@ def test_mask_only_steps_equal_steps_that_return_the_prediction(vos, dev, layout
     assert len({int(m.sum()) for m in masks[False]}) > 1
 
 
+@pytest.mark.parametrize('H,W,d', [(8, 8, 2), (40, 56, 3), (64, 64, 16), (136, 152, 16), (100, 131, 1), (216, 152, 4)],
+                         ids=['1x1', '5x7', '8x8_16cls', '17x19_16cls', '13x17_1cls', '27x19'])
+def test_mask_only_steps_at_edge_shapes(vos, dev, H, W, d):
+    """prop_mask_kernel where its segment logic has no room: a single pixel (one tile step per segment: no step boundary at all),
+    maps smaller than one reference tile, exactly 16 classes (every row of the 16x16x32 label fragment in use), one class, a
+    27x19 map (513 pixels: the last target tile holds a single column, seven staging-only waves).  An 8-frame roll-out of mask-only
+    steps (the engine must report prop_mask_kernel) against the roll-out that returns predictions (prop_dense_kernel): the two are
+    different roundings of the same sums, near-ties may fall either way - at most 2 % of the pixels at these sizes, and every class
+    index valid."""
+    Hd, Wd = vos.feature_map_size(H, W)
+    rs = np.random.RandomState(H * W + d)
+    ann = (rs.randint(0, d, size=(Hd, Wd)).astype(np.uint8)).repeat(8, 0).repeat(8, 1)[:H, :W]
+    ann[0, 0] = d - 1
+    base = rs.randn(256, Hd, Wd).astype(np.float32)
+    feats = []
+    for _ in range(8):
+        base = 0.9 * base + 0.45 * rs.randn(256, Hd, Wd).astype(np.float32)
+        feats.append(torch.from_numpy(base * 0.25).to(dev))
+    masks = {}
+    for want_pred in (True, False):
+        eng = vos.PropagationEngine(Hd, Wd, device=0, ref_num=9)
+        eng.begin_video(ann)
+        masks[want_pred] = [eng.step(f, want_pred=want_pred, want_mask=True)[1] for f in feats][1:]
+        st = eng.last_stats()
+        eng.close()
+        assert st['kernel_id'] == (vos._native.KERNEL_DENSE if want_pred else vos._native.KERNEL_MASK), st
+    for a, b in zip(masks[True], masks[False]):
+        assert int(b.max()) < d
+        assert float((a != b).float().mean()) <= 2e-2, float((a != b).float().mean())
+
+
 def test_step_writes_the_mask_into_a_caller_buffer(vos, dev):
     """engine.step(mask_out=...) writes the mask into the caller's (H, W) uint8 buffer (a slice of a batch buffer that goes back to
     the host in one copy, bench.py end_to_end) - the same mask a plain step returns; a buffer of the wrong shape is refused."""
